@@ -1,0 +1,420 @@
+#!/opt/conda/bin/python3.9
+"""Generate tests/golden/*.npz by importing the REAL reference (build container only).
+
+    /opt/conda/bin/python3.9 oracle/refimport/make_golden.py [g1 g2 ...]
+
+TEST INFRASTRUCTURE.  The reference (``/root/reference``) is imported here,
+unmodified, under the conda interpreter (NumPy 1.26.4; the system interpreter
+cannot import it: tkinter, cv2 and ``np.infty`` are missing there) with
+``oracle/refimport/cv2.py`` standing in for the one OpenCV call on the path
+(``pyrDown``, PARITY UNPINNED -- see that file).  Only arrays leave this
+script: inputs and the reference's outputs, written as small ``.npz`` files.
+Nothing under ``/root/reference`` is copied, and nothing here runs on the GPU
+box (the reference does not exist there).
+
+What the files hold:
+  g1_small      64x96 / 50x70 frames x 5 contents x 4 searches x 2 norms x 4 (bs,sw)
+  g2_synth720   synthetic 720x480 pair (seed 1234, t=0,1): 4 searches x 2 norms
+  g3_docframes  race (720x480) and pan240 (320x240) doc frames: 4 searches x 2 norms
+  g4_gme        GME stage dumps (dense MF, params0, per level gt/model/mask/F/S/params,
+                final field, compensated frame, PSNR) on g2/g3 inputs + a small pair
+  g5_1080p      synthetic 1920x1080 (seed 4321): GME stage dump, exhaustive MSE sw=32
+  g6_edges      affine fields for random parameters, compensate on ragged shapes,
+                first-parameter means, degenerate fits, 2D-log sw in {1,2,3}, PSNR
+  g7_sequence   6-frame 128x192 synthetic sequence, frame distance 1 and 2: params,
+                compensated-frame hashes, PSNR per pair (results.py:41-112 flow)
+"""
+import hashlib
+import os
+import sys
+import time
+import warnings
+from multiprocessing import Pool
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/global_motion_estimation"
+sys.path[:0] = [HERE, REF, os.path.join(REPO, "global-motion-estimation_amd")]
+warnings.filterwarnings("ignore")
+
+import numpy as np          # noqa: E402
+import bbme                 # noqa: E402  (the reference)
+import motion               # noqa: E402  (the reference)
+import utils                # noqa: E402  (the reference)
+import synth                # noqa: E402  (this repo's input generator)
+
+OUT = os.path.join(REPO, "tests", "golden")
+DOC = "/root/reference/docs/assets/images"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_png(name):
+    from PIL import Image
+    im = Image.open(os.path.join(DOC, name))
+    assert im.mode == "L", im.mode
+    return np.array(im, dtype=np.uint8)
+
+
+def _mf_job(args):
+    prev, cur, bs, sw, sp, pn = args
+    return bbme.get_motion_field(prev, cur, block_size=bs, search_window=sw,
+                                 searching_procedure=sp, pnorm_distance=pn)
+
+
+def all_searches(pool, prev, cur, bs, sw):
+    jobs = [(prev, cur, bs, sw, sp, pn) for sp in range(4) for pn in range(2)]
+    res = pool.map(_mf_job, jobs)
+    return {"mf_sp%d_pn%d" % (j[4], j[5]): r for j, r in zip(jobs, res)}
+
+
+# --------------------------------------------------------------------------
+def small_inputs():
+    rng = np.random.default_rng(20261004)
+    out = {}
+    for (h, w) in ((64, 96), (50, 70)):
+        base = rng.integers(0, 256, (h + 16, w + 16), dtype=np.uint8)
+        # smooth texture so that shifted content has a well-defined best match
+        smooth = base.astype(np.int32)
+        smooth = (smooth + np.roll(smooth, 1, 0) + np.roll(smooth, 1, 1) + np.roll(smooth, (1, 1), (0, 1))) // 4
+        smooth = smooth.astype(np.uint8)
+        tag = "%dx%d" % (h, w)
+        out["random_" + tag] = (rng.integers(0, 256, (h, w), dtype=np.uint8),
+                                rng.integers(0, 256, (h, w), dtype=np.uint8))
+        f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        out["identical_" + tag] = (f, f.copy())
+        out["flat_" + tag] = (np.full((h, w), 77, np.uint8), np.full((h, w), 77, np.uint8))
+        out["shifted_" + tag] = (smooth[8:8 + h, 8:8 + w].copy(), smooth[8 - 3:8 - 3 + h, 8 + 2:8 + 2 + w].copy())
+        q = (smooth // 64 * 64).astype(np.uint8)      # coarse quantisation: many ties
+        out["quant_" + tag] = (q[8:8 + h, 8:8 + w].copy(), q[8 + 1:8 + 1 + h, 8 - 2:8 - 2 + w].copy())
+    return out
+
+
+def g1(pool):
+    inputs = small_inputs()
+    data = {}
+    jobs, keys = [], []
+    for name, (p, c) in inputs.items():
+        data["in_%s_prev" % name] = p
+        data["in_%s_cur" % name] = c
+        for (bs, sw) in ((16, 16), (4, 2), (8, 7), (2, 3)):
+            for sp in range(4):
+                for pn in range(2):
+                    jobs.append((p, c, bs, sw, sp, pn))
+                    keys.append("mf_%s_bs%d_sw%d_sp%d_pn%d" % (name, bs, sw, sp, pn))
+    for k, r in zip(keys, pool.map(_mf_job, jobs, chunksize=4)):
+        data[k] = r
+    np.savez_compressed(os.path.join(OUT, "g1_small.npz"), **data)
+
+
+def g2(pool):
+    p, c = synth.frame(1234, 0, 480, 720), synth.frame(1234, 1, 480, 720)
+    data = {"sha_prev": sha(p), "sha_cur": sha(c)}
+    data.update(all_searches(pool, p, c, 16, 16))
+    np.savez_compressed(os.path.join(OUT, "g2_synth720.npz"), **data)
+
+
+def g3(pool):
+    data = {}
+    for tag, (a, b) in (("race", ("race-previous.png", "race-current.png")),
+                        ("pan240", ("pan240-prev-frame.png", "pan240-curr-frame.png"))):
+        p, c = load_png(a), load_png(b)
+        data["in_%s_prev" % tag] = p
+        data["in_%s_cur" % tag] = c
+        for k, v in all_searches(pool, p, c, 16, 16).items():
+            data["%s_%s" % (tag, k)] = v
+    np.savez_compressed(os.path.join(OUT, "g3_docframes.npz"), **data)
+
+
+# --------------------------------------------------------------------------
+class _NumpyTap:
+    """Forwards to numpy but records the operands of the 3x3 solve (motion.py:262-264,280-282)."""
+
+    def __init__(self, log):
+        self._log = log
+        self.linalg = self
+
+    def inv(self, m):
+        self._log.append(("F", np.array(m, dtype=np.float64)))
+        return np.linalg.inv(m)
+
+    def matmul(self, a, b):
+        if np.shape(a) == (3, 3) and np.shape(b) == (3, 1):
+            self._log.append(("S", np.array(b, dtype=np.float64).reshape(3)))
+        return np.matmul(a, b)
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+def gme_stage_dump(prev, cur, prefix, data, bbme_bs=16):
+    """Run the reference GME with taps on its internal calls; store every stage."""
+    log = []
+    calls = []
+    real_gmf, real_aff = motion.get_motion_field, motion.get_motion_field_affine
+
+    def tap_gmf(*a, **k):
+        r = real_gmf(*a, **k)
+        calls.append(("gt", r.copy()))
+        return r
+
+    def tap_aff(shape, parameters):
+        r = real_aff(shape, parameters)
+        calls.append(("model", r.copy(), np.array(parameters, copy=True)))
+        return r
+
+    old_bs = motion.BBME_BLOCK_SIZE
+    motion.BBME_BLOCK_SIZE = bbme_bs
+    motion.get_motion_field, motion.get_motion_field_affine = tap_gmf, tap_aff
+    motion.np = _NumpyTap(log)
+    try:
+        params = motion.global_motion_estimation(prev, cur)
+    finally:
+        motion.get_motion_field, motion.get_motion_field_affine = real_gmf, real_aff
+        motion.np = np
+    gts = [c for c in calls if c[0] == "gt"]
+    models = [c for c in calls if c[0] == "model"]
+    assert len(gts) == 3 and len(models) == 2 and len(log) == 8, (len(gts), len(models), len(log))
+    pp, cp = utils.get_pyramids(prev), utils.get_pyramids(cur)
+    data[prefix + "pyr_sha"] = np.array([sha(x) for x in pp + cp])
+    data[prefix + "dense"] = gts[0][1]
+    data[prefix + "params0"] = motion.compute_first_parameters(gts[0][1])
+    for lvl in (1, 2):
+        gt, model, pin = gts[lvl][1], models[lvl - 1][1], models[lvl - 1][2]
+        diff = np.abs(gt - model).sum(axis=2)
+        srt = np.sort(diff.flatten())
+        thr = srt[-int(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE * len(srt))]
+        ent = log[(lvl - 1) * 4:(lvl - 1) * 4 + 4]
+        assert [e[0] for e in ent] == ["F", "S", "F", "S"]
+        assert np.array_equal(ent[0][1], ent[2][1])
+        data[prefix + "l%d_gt" % lvl] = gt
+        data[prefix + "l%d_model" % lvl] = model
+        data[prefix + "l%d_params_in" % lvl] = pin
+        data[prefix + "l%d_thr" % lvl] = np.int64(thr)
+        data[prefix + "l%d_mask" % lvl] = diff > thr
+        data[prefix + "l%d_F" % lvl] = ent[0][1]
+        data[prefix + "l%d_Sx" % lvl] = ent[1][1]
+        data[prefix + "l%d_Sy" % lvl] = ent[3][1]
+    data[prefix + "params"] = params
+    motion.BBME_BLOCK_SIZE = bbme_bs
+    try:
+        shape = (prev.shape[0] // bbme_bs, prev.shape[1] // bbme_bs)
+        field = motion.get_motion_field_affine(shape, params)
+        comp = motion.compensate_frame(prev, field)
+        comp2 = motion.motion_compensation(prev, cur)
+    finally:
+        motion.BBME_BLOCK_SIZE = old_bs
+    assert np.array_equal(comp, comp2)
+    data[prefix + "field"] = field
+    data[prefix + "comp_sha"] = sha(comp)
+    data[prefix + "psnr"] = np.float64(utils.PSNR(cur, comp).real)
+    data[prefix + "psnr_prev"] = np.float64(utils.PSNR(cur, prev).real)
+    return params, comp
+
+
+def _g4_job(tag):
+    data = {}
+    if tag == "synth720":
+        p, c = synth.frame(1234, 0, 480, 720), synth.frame(1234, 1, 480, 720)
+    elif tag == "race":
+        p, c = load_png("race-previous.png"), load_png("race-current.png")
+    elif tag == "pan240":
+        p, c = load_png("pan240-prev-frame.png"), load_png("pan240-curr-frame.png")
+    elif tag == "dp":
+        p, c = load_png("dp-previous.png"), load_png("dp-current.png")
+        data["in_dp_prev"], data["in_dp_cur"] = p, c
+    elif tag == "small":
+        p, c = synth.frame(77, 3, 128, 192), synth.frame(77, 4, 128, 192)
+    elif tag == "bs12":
+        # the authors' figures use a monkey-patched block size (presentation/main.tex:382)
+        p, c = synth.frame(78, 0, 240, 320), synth.frame(78, 2, 240, 320)
+        _, comp = gme_stage_dump(p, c, "bs12_", data, bbme_bs=12)
+        data["bs12_comp"] = comp
+        return data
+    _, comp = gme_stage_dump(p, c, tag + "_", data)
+    if tag in ("small", "pan240"):
+        data[tag + "_comp"] = comp
+    return data
+
+
+def g4(pool):
+    data = {}
+    for d in pool.map(_g4_job, ["synth720", "race", "pan240", "dp", "small", "bs12"]):
+        data.update(d)
+    np.savez_compressed(os.path.join(OUT, "g4_gme.npz"), **data)
+
+
+def _g5_gme(_):
+    data = {}
+    p, c = synth.frame(4321, 0, 1080, 1920), synth.frame(4321, 1, 1080, 1920)
+    data["sha_prev"], data["sha_cur"] = sha(p), sha(c)
+    gme_stage_dump(p, c, "gme_", data)
+    return data
+
+
+def _g5_strip(args):
+    """Reference exhaustive MSE sw=32 on a strip whose interior block rows see the
+    same candidates as in the full frame (window fully inside the strip)."""
+    r_lo, r_hi, top, bot = args
+    p, c = synth.frame(4321, 0, 1080, 1920), synth.frame(4321, 1, 1080, 1920)
+    mf = bbme.get_motion_field(p[top:bot], c[top:bot], block_size=16, search_window=32,
+                               searching_procedure=0, pnorm_distance=1)
+    return r_lo, r_hi, (r_lo * 16 - top) // 16, mf
+
+
+def g5(pool):
+    data = pool.apply_async(_g5_gme, (0,))
+    # exhaustive MSE bs=16 sw=32 on 1080p: ~200 s single-core for the whole frame.
+    # The frame is cut into strips of block rows; a strip [top, bot) is valid for
+    # block row br iff every candidate row the full-frame search may use for br,
+    # [16*br-32, 16*br+16+47-1+... ] clipped to the frame, lies inside the strip,
+    # and the strip edges coincide with frame edges or lie beyond the window.
+    H, bs, sw = 1080, 16, 32
+    nbr = H // bs                      # 67
+    jobs = []
+    per = 9
+    for lo in range(0, nbr, per):
+        hi = min(nbr, lo + per)
+        top = max(0, lo * bs - sw)
+        bot = min(H, (hi - 1) * bs + (sw + bs - 1) + bs)      # last candidate row + bs
+        # top must stay block-aligned so that strip block rows map onto frame block rows
+        top -= top % bs
+        jobs.append((lo, hi, top, bot))
+    mf = np.zeros((nbr, 1920 // bs, 2), np.int32)
+    for lo, hi, off, part in pool.map(_g5_strip, jobs):
+        mf[lo:hi] = part[off:off + (hi - lo)]
+    out = data.get()
+    out["exh_mse_sw32"] = mf
+    np.savez_compressed(os.path.join(OUT, "g5_1080p.npz"), **out)
+
+
+# --------------------------------------------------------------------------
+def g6(pool):
+    rng = np.random.default_rng(606)
+    data = {}
+    # affine fields: random float64 / float32 parameters incl. half-integer traps
+    plist = []
+    for k in range(24):
+        p = rng.normal(0, 1, 6) * np.array([8, .05, .05, 8, .05, .05])
+        if k % 4 == 1:
+            p = p.astype(np.float32)
+        if k % 4 == 2:
+            p[[0, 3]] = np.round(p[[0, 3]]) + 0.5
+            p[[1, 2, 4, 5]] = rng.choice([0.0, 0.5, -0.25, 1e-17, -1e-16], 4)
+        if k % 4 == 3:
+            p[[1, 2, 4, 5]] *= 1e-14
+        plist.append(p)
+    for k, p in enumerate(plist):
+        shape = [(30, 45), (15, 22), (67, 120), (3, 5)][k % 4]
+        data["aff_p_%d" % k] = p
+        data["aff_f_%d" % k] = motion.get_motion_field_affine(shape, p)
+    # three-tuple shape as results.py:53 passes it
+    data["aff_f_tuple3"] = motion.get_motion_field_affine((4, 6, 2), plist[0])
+    # compensate_frame on ragged shapes and wild vectors
+    for k, (h, w, bs) in enumerate(((64, 96, 16), (50, 70, 16), (37, 53, 8), (48, 80, 12), (33, 47, 16))):
+        f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        mfs = (h // bs, w // bs)
+        mf16 = rng.integers(-40, 41, mfs + (2,)).astype(np.int16)
+        mf32 = rng.integers(-h, h, mfs + (2,)).astype(np.int32)
+        data["comp_in_%d" % k] = f
+        data["comp_mf16_%d" % k] = mf16
+        data["comp_out16_%d" % k] = motion.compensate_frame(f, mf16)
+        data["comp_mf32_%d" % k] = mf32
+        data["comp_out32_%d" % k] = motion.compensate_frame(f, mf32)
+    # field narrower than the frame (bs from the height only, motion.py:303)
+    f = rng.integers(0, 256, (64, 100), dtype=np.uint8)
+    mf = rng.integers(-9, 10, (4, 4, 2)).astype(np.int16)
+    data["comp_in_narrow"], data["comp_mf_narrow"] = f, mf
+    data["comp_out_narrow"] = motion.compensate_frame(f, mf)
+    # field wider than the frame allows (bs=16 from the height, 8 columns -> 128 > 100)
+    mf = rng.integers(-9, 10, (4, 8, 2)).astype(np.int16)
+    data["comp_mf_wide"] = mf
+    data["comp_out_wide"] = motion.compensate_frame(f, mf)
+    # first parameters (float32 of float64 means)
+    for k in range(4):
+        d = rng.integers(-7, 8, (60 + k, 90 - k, 2)).astype(np.int32)
+        data["fp_in_%d" % k] = d
+        data["fp_out_%d" % k] = motion.compute_first_parameters(d)
+    # parameter projection keeps dtype and works in place
+    p32 = np.array([1.3, .1, .2, -2.7, .3, .4], np.float32)
+    q = motion.parameter_projection(p32)
+    data["proj32"] = q
+    assert q is p32
+    # PSNR
+    a = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-9, 10, a.shape), 0, 255).astype(np.uint8)
+    data["psnr_a"], data["psnr_b"] = a, b
+    data["psnr_ab"] = np.float64(utils.PSNR(a, b).real)
+    data["psnr_aa"] = np.float64(utils.PSNR(a, a))
+    # robust fit on tiny fields: threshold index 0 (N < 4) and a singular system
+    for tag, (h, w) in (("n6", (32, 48)), ("n3", (31, 63)), ("n4", (47, 40))):
+        p = synth.frame(5, 0, h, w)
+        c = synth.frame(5, 1, h, w)
+        data["fit_%s_prev" % tag], data["fit_%s_cur" % tag] = p, c
+        pin = np.array([1.0, 0, 0, -1.0, 0, 0], np.float32)
+        try:
+            r = motion.best_affine_parameters_robust(p, c, pin.copy())
+            data["fit_%s_out" % tag] = r
+            data["fit_%s_err" % tag] = ""
+        except Exception as e:        # numpy.linalg.LinAlgError expected for singular F
+            data["fit_%s_err" % tag] = type(e).__name__
+    # 2D-log degenerate windows and three-step with out-of-frame third step
+    p, c = small_inputs()["shifted_64x96"]
+    for sw in (1, 2, 3):
+        data["tdl_sw%d" % sw] = bbme.get_motion_field(p, c, block_size=8, search_window=sw,
+                                                      searching_procedure=2, pnorm_distance=0)
+    p, c = small_inputs()["random_50x70"]
+    data["tss_wild"] = bbme.get_motion_field(p, c, block_size=4, search_window=20,
+                                             searching_procedure=1, pnorm_distance=1)
+    data["tss_default"] = bbme.get_motion_field(p, c)          # all defaults (bs 4, sw 2, TSS, MSE)
+    # MSE with bs = 32 leaves the exact-integer float32 range (SURVEY §7 hard part 3)
+    p = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    c = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    data["bs32_prev"], data["bs32_cur"] = p, c
+    for sp in (0, 3):
+        data["bs32_sp%d" % sp] = bbme.get_motion_field(p, c, block_size=32, search_window=4,
+                                                       searching_procedure=sp, pnorm_distance=1)
+    # high-contrast pair where bs=32 MSE costs exceed 2**24 and float32 rounding bites
+    p = (rng.integers(0, 2, (96, 128)) * 255).astype(np.uint8)
+    c = (rng.integers(0, 2, (96, 128)) * 255).astype(np.uint8)
+    data["bs32hc_prev"], data["bs32hc_cur"] = p, c
+    for sp in (0, 3):
+        data["bs32hc_sp%d" % sp] = bbme.get_motion_field(p, c, block_size=32, search_window=6,
+                                                         searching_procedure=sp, pnorm_distance=1)
+    np.savez_compressed(os.path.join(OUT, "g6_edges.npz"), **data)
+
+
+def _g7_job(args):
+    fd, i = args
+    frames = synth.sequence(2000, 0, 6, 128, 192)
+    prev, cur = frames[i - fd], frames[i]
+    params = motion.global_motion_estimation(prev, cur)
+    field = motion.get_motion_field_affine(
+        (int(prev.shape[0] / motion.BBME_BLOCK_SIZE), int(prev.shape[1] / motion.BBME_BLOCK_SIZE), 2),
+        parameters=params)
+    comp = motion.compensate_frame(prev, field)
+    return fd, i, params, field, comp, utils.PSNR(cur, comp).real
+
+
+def g7(pool):
+    data = {"frames_sha": sha(synth.sequence(2000, 0, 6, 128, 192))}
+    jobs = [(fd, i) for fd in (1, 2) for i in range(fd, 6)]
+    for fd, i, params, field, comp, ps in pool.map(_g7_job, jobs):
+        k = "fd%d_i%d_" % (fd, i)
+        data[k + "params"] = params
+        data[k + "field"] = field
+        data[k + "comp"] = comp
+        data[k + "psnr"] = np.float64(ps)
+    np.savez_compressed(os.path.join(OUT, "g7_sequence.npz"), **data)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    os.makedirs(OUT, exist_ok=True)
+    with Pool(8) as pool:
+        for name in which:
+            t = time.time()
+            globals()[name](pool)
+            print("%s done in %.1fs" % (name, time.time() - t), flush=True)
