@@ -1,0 +1,355 @@
+"""ctypes binding of libgme_hip.so (include/gme_hip.h) -- the only way the Python
+surface reaches the GPU.  No PyTorch, no fallback: if the library or a gfx950 device
+is missing every call raises.
+
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C global-motion-estimation_amd/csrc``.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgme_hip.so")
+
+GME_OK, ERR_ARG, ERR_INEXACT, ERR_GEOMETRY, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class GmeError(RuntimeError):
+    """HIP/runtime failure inside libgme_hip.so."""
+
+
+class GmeInexactError(ArithmeticError):
+    """The requested block size / norm leaves float32's exact-integer range, where the
+    reference's own result depends on NumPy's summation order (bbme.py:61-64)."""
+
+
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_i16p = ctypes.POINTER(ctypes.c_int16)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+_SIGNATURES = {
+    "gme_last_error": (ctypes.c_char_p, []),
+    "gme_device_count": (_i, []),
+    "gme_create": (_vp, [_i]),
+    "gme_destroy": (None, [_vp]),
+    "gme_sync": (_i, [_vp]),
+    "gme_stream": (_vp, [_vp]),
+    "gme_device_info": (_i, [_vp, ctypes.c_char_p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "gme_timer_start": (_i, [_vp]),
+    "gme_timer_stop": (_i, [_vp, _c_f32p]),
+    "gme_bbme_u8": (_i, [_vp, _c_u8p, _c_u8p, _i, _i, _i, _i, _i, _i, _i, _c_i32p]),
+    "gme_pyrdown_u8": (_i, [_vp, _c_u8p, _i, _i, _i, _c_u8p]),
+    "gme_affine_field": (_i, [_vp, _c_f64p, _i, _i, _c_i16p]),
+    "gme_compensate_u8": (_i, [_vp, _c_u8p, _i, _i, _i, _c_i32p, _i, _i, _c_u8p]),
+    "gme_sse_u8": (_i, [_vp, _c_u8p, _c_u8p, _i, _i, _i, _i, _c_i64p]),
+    "gme_seq_create": (_vp, [_vp, _i, _i, _i]),
+    "gme_seq_destroy": (None, [_vp]),
+    "gme_seq_upload": (_i, [_vp, _i, _i, _c_u8p, _i, ctypes.c_int64]),
+    "gme_seq_synth": (_i, [_vp, ctypes.c_uint64, _i]),
+    "gme_seq_read_frame": (_i, [_vp, _i, _i, _c_u8p]),
+    "gme_seq_bbme": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "gme_seq_read_mv": (_i, [_vp, _i, _i, _c_i32p]),
+    "gme_seq_gme_begin": (_i, [_vp, _i, _i, _i, _i, _c_f32p]),
+    "gme_seq_gme_fit": (_i, [_vp, _i, _c_f64p, ctypes.c_double, _c_f64p]),
+    "gme_seq_gme_read_stage": (_i, [_vp, _i, _i, _c_i32p, _c_i16p, _c_u8p, _c_i64p]),
+    "gme_seq_compensate": (_i, [_vp, _i, _i, _c_f64p, _c_i64p]),
+    "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def exported_symbols():
+    """Names include/gme_hip.h declares (used by the CPU-side symbol test)."""
+    return sorted(_SIGNATURES)
+
+
+def load_library():
+    """dlopen libgme_hip.so and attach signatures; never touches a device."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GmeError(
+                "libgme_hip.so is not built (%s). Build it with `make -C %s`; this package has no "
+                "CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _raise(rc, lib):
+    msg = (lib.gme_last_error() or b"").decode("utf-8", "replace")
+    if rc == ERR_ARG:
+        raise IndexError(msg)            # bbme.py:27,60 raise IndexError on bad table indices
+    if rc == ERR_INEXACT:
+        raise GmeInexactError(msg)
+    if rc == ERR_GEOMETRY:
+        raise AssertionError(msg)        # bbme.py:59
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise GmeError("libgme_hip: %s (code %d)" % (msg, rc))
+
+
+def _check(rc, lib):
+    if rc != GME_OK:
+        _raise(rc, lib)
+
+
+def as_frame(a, name="frame"):
+    """2-D C-contiguous uint8 view/copy of `a` (the reference feeds grayscale uint8, utils.py:26-28)."""
+    a = np.asarray(a)
+    if a.ndim != 2:
+        raise ValueError("%s must be a 2-D grayscale image, got shape %r" % (name, a.shape))
+    if a.dtype != np.uint8:
+        raise TypeError("%s must be uint8 (got %s): the device kernels are integer-exact on 8-bit luma" % (name, a.dtype))
+    if a.strides[1] != 1 or a.strides[0] < a.shape[1]:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One device + one HIP stream (gme_ctx)."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("GME_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = self.lib.gme_device_count()
+            if n > 0:
+                device %= n
+        self.device = device
+        self.handle = self.lib.gme_create(device)
+        if not self.handle:
+            raise GmeError("cannot open HIP device %d: %s" % (device, self.lib.gme_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gme_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- misc
+    def sync(self):
+        _check(self.lib.gme_sync(self.handle), self.lib)
+
+    def info(self):
+        name = ctypes.create_string_buffer(128)
+        cu, clk = _i(0), _i(0)
+        _check(self.lib.gme_device_info(self.handle, name, 128, ctypes.byref(cu), ctypes.byref(clk)), self.lib)
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_khz": clk.value}
+
+    def timer_start(self):
+        _check(self.lib.gme_timer_start(self.handle), self.lib)
+
+    def timer_stop(self):
+        ms = ctypes.c_float(0)
+        _check(self.lib.gme_timer_stop(self.handle, ctypes.byref(ms)), self.lib)
+        return ms.value
+
+    # ---- single-pair calls
+    def bbme(self, prev, cur, block_size, search_window, procedure, pnorm):
+        prev, cur = as_frame(prev, "previous"), as_frame(cur, "current")
+        if prev.shape != cur.shape:
+            raise AssertionError("previous and current differ in shape (bbme.py:59)")
+        H, W = prev.shape
+        if cur.strides[0] != prev.strides[0]:
+            cur = np.ascontiguousarray(cur)
+            prev = np.ascontiguousarray(prev)
+        mf = np.zeros((int(H / block_size), int(W / block_size), 2), dtype=np.int32)
+        _check(self.lib.gme_bbme_u8(self.handle, _p(prev, _c_u8p), _p(cur, _c_u8p), H, W, prev.strides[0],
+                                    block_size, search_window, procedure, pnorm, _p(mf, _c_i32p)), self.lib)
+        return mf
+
+    def pyrdown(self, img):
+        img = as_frame(img, "image")
+        H, W = img.shape
+        out = np.empty(((H + 1) // 2, (W + 1) // 2), dtype=np.uint8)
+        _check(self.lib.gme_pyrdown_u8(self.handle, _p(img, _c_u8p), H, W, img.strides[0], _p(out, _c_u8p)), self.lib)
+        return out
+
+    def affine_field(self, params, h, w):
+        p = np.ascontiguousarray(np.asarray(params).astype(np.float64).reshape(6))
+        out = np.zeros((h, w, 2), dtype=np.int16)
+        _check(self.lib.gme_affine_field(self.handle, _p(p, _c_f64p), h, w, _p(out, _c_i16p)), self.lib)
+        return out
+
+    def compensate(self, frame, mf):
+        frame = as_frame(frame)
+        mf32 = np.ascontiguousarray(np.asarray(mf)[:, :, :2].astype(np.int32))
+        H, W = frame.shape
+        out = np.empty((H, W), dtype=np.uint8)
+        _check(self.lib.gme_compensate_u8(self.handle, _p(frame, _c_u8p), H, W, frame.strides[0], _p(mf32, _c_i32p),
+                                          mf32.shape[0], mf32.shape[1], _p(out, _c_u8p)), self.lib)
+        return out
+
+    def sse(self, a, b):
+        a, b = as_frame(a, "original"), as_frame(b, "noisy")
+        if a.shape != b.shape:
+            raise ValueError("operands could not be broadcast together with shapes %r %r" % (a.shape, b.shape))
+        v = ctypes.c_int64(0)
+        _check(self.lib.gme_sse_u8(self.handle, _p(a, _c_u8p), _p(b, _c_u8p), a.shape[0], a.shape[1], a.strides[0],
+                                   b.strides[0], ctypes.byref(v)), self.lib)
+        return v.value
+
+
+class Sequence:
+    """N frames resident in HBM (gme_seq) and the per-pair results computed from them."""
+
+    def __init__(self, ctx, n_frames, height, width):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.N, self.H, self.W = int(n_frames), int(height), int(width)
+        self.handle = self.lib.gme_seq_create(ctx.handle, self.N, self.H, self.W)
+        if not self.handle:
+            raise GmeError("gme_seq_create failed: %s" % self.lib.gme_last_error().decode())
+        self._gme = None
+
+    @classmethod
+    def from_frames(cls, ctx, frames):
+        frames = [as_frame(f) for f in frames] if not isinstance(frames, np.ndarray) else frames
+        if isinstance(frames, np.ndarray):
+            if frames.ndim != 3 or frames.dtype != np.uint8:
+                raise TypeError("frames must be uint8[N, H, W]")
+            frames = np.ascontiguousarray(frames)
+            seq = cls(ctx, frames.shape[0], frames.shape[1], frames.shape[2])
+            seq.upload(0, frames)
+            return seq
+        seq = cls(ctx, len(frames), *frames[0].shape)
+        for k, f in enumerate(frames):
+            if f.shape != frames[0].shape:
+                raise ValueError("all frames of a sequence must share one shape")
+            seq.upload(k, np.ascontiguousarray(f)[None])
+        return seq
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gme_seq_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, first, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, H, W = frames.shape
+        if (H, W) != (self.H, self.W):
+            raise ValueError("frame shape %r does not match the sequence %r" % ((H, W), (self.H, self.W)))
+        _check(self.lib.gme_seq_upload(self.handle, first, n, _p(frames, _c_u8p), W, H * W), self.lib)
+
+    def synth(self, seed, t0=0):
+        _check(self.lib.gme_seq_synth(self.handle, seed, t0), self.lib)
+
+    def level_shape(self, level):
+        h, w = self.H, self.W
+        for _ in range(2 - level):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        return h, w
+
+    def read_frame(self, index, level=2):
+        out = np.empty(self.level_shape(level), dtype=np.uint8)
+        _check(self.lib.gme_seq_read_frame(self.handle, level, index, _p(out, _c_u8p)), self.lib)
+        return out
+
+    # ---- BBME over all pairs
+    def bbme(self, frame_distance, block_size, search_window, procedure, pnorm):
+        _check(self.lib.gme_seq_bbme(self.handle, frame_distance, block_size, search_window, procedure, pnorm), self.lib)
+        self._mv_shape = (self.N - frame_distance, int(self.H / block_size), int(self.W / block_size), 2)
+
+    def read_mv(self, first=0, count=None):
+        pairs = self._mv_shape[0]
+        count = pairs - first if count is None else count
+        out = np.empty((count,) + self._mv_shape[1:], dtype=np.int32)
+        if out.size:
+            _check(self.lib.gme_seq_read_mv(self.handle, first, count, _p(out, _c_i32p)), self.lib)
+        return out
+
+    # ---- GME stages
+    def gme_begin(self, frame_distance, bbme_block_size, procedure=3, search_window=2):
+        pairs = self.N - frame_distance
+        p0 = np.empty((max(pairs, 0), 6), dtype=np.float32)
+        _check(self.lib.gme_seq_gme_begin(self.handle, frame_distance, bbme_block_size, procedure, search_window,
+                                          _p(p0, _c_f32p)), self.lib)
+        self._gme = (frame_distance, bbme_block_size, pairs)
+        return p0
+
+    def gme_fit(self, level, params_in, outlier_fraction):
+        """-> sums float64[P, 15] = F (9) | Sx (3) | Sy (3).  level -1 fits the field of the
+        last bbme() call against the full-resolution frame size."""
+        pairs = self._gme[2] if level >= 0 else self._mv_shape[0]
+        p = np.ascontiguousarray(np.asarray(params_in, dtype=np.float64).reshape(pairs, 6))
+        sums = np.empty((pairs, 15), dtype=np.float64)
+        _check(self.lib.gme_seq_gme_fit(self.handle, level, _p(p, _c_f64p), float(outlier_fraction), _p(sums, _c_f64p)),
+               self.lib)
+        return sums
+
+    def stage_shape(self, level):
+        if level < 0:
+            return self._mv_shape[1:3]
+        h, w = self.level_shape(level)
+        bs = 2 if level == 0 else self._gme[1]
+        return int(h / bs), int(w / bs)
+
+    def gme_read_stage(self, level, pair):
+        h, w = self.stage_shape(level)
+        gt = np.empty((h, w, 2), dtype=np.int32)
+        model = np.empty((h, w, 2), dtype=np.int16)
+        mask = np.empty((h, w), dtype=np.uint8)
+        thr = ctypes.c_int64(0)
+        _check(self.lib.gme_seq_gme_read_stage(self.handle, level, pair, _p(gt, _c_i32p), _p(model, _c_i16p),
+                                               _p(mask, _c_u8p), ctypes.byref(thr)), self.lib)
+        if level == 0:
+            return {"gt": gt}
+        return {"gt": gt, "model": model, "mask": mask.astype(bool), "thr": thr.value}
+
+    # ---- compensation + squared error
+    def compensate(self, frame_distance, block_size, params):
+        pairs = self.N - frame_distance
+        p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(pairs, 6))
+        sse = np.empty(pairs, dtype=np.int64)
+        _check(self.lib.gme_seq_compensate(self.handle, frame_distance, block_size, _p(p, _c_f64p), _p(sse, _c_i64p)),
+               self.lib)
+        return sse
+
+    def read_compensated(self, pair):
+        out = np.empty((self.H, self.W), dtype=np.uint8)
+        _check(self.lib.gme_seq_read_compensated(self.handle, pair, _p(out, _c_u8p)), self.lib)
+        return out
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context used by the module-level functions of bbme/motion/utils."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Context()
+        return _default

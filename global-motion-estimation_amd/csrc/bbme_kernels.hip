@@ -1,0 +1,301 @@
+// Block-matching motion estimation kernels for gfx950 (MI355X).
+//
+// Replaces bbme.py:105-534 of the reference (exhaustive, three-step, 2-D log and
+// diamond searches under MAE / MSE).  All block distances are exact integers, which
+// equals the reference's float32 arithmetic inside the bounds checked by
+// bbme_check_args() (bbme.py:61-64; SURVEY.md §7 hard part 3).
+//
+// Kernels
+//   k_exh_qsad16<R>   exhaustive MAE, bs = 16: one wavefront per macroblock, the
+//                     anchor block in SGPRs, the search window staged in LDS, the
+//                     4-offset sliding SAD instruction v_qsad_pk_u16_u8 in the loop,
+//                     packed (cost, scan index) keys min-reduced across the wave.
+//   k_exh_generic     exhaustive, any geometry / norm (one 256-thread group per block)
+//   k_walk<G>         three-step / 2-D log / diamond walks, G lanes per block
+#include "gme_internal.h"
+
+namespace {
+
+struct Dev {
+    const uint8_t* prev;
+    const uint8_t* cur;
+    long long plane_stride;
+    int pairs, H, W, pitch, bs, sw, pnorm, procedure;
+    int nbr, nbc;
+    int32_t* mf;
+    int* status;
+};
+
+__device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b)
+{
+    return a < b ? a : b;
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// generic exhaustive search (bbme.py:105-179)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_exh_generic(Dev d)
+{
+    __shared__ unsigned long long wave_best[4];
+    const int nblk = d.nbr * d.nbc;
+    const int pair = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int r0 = (blk / d.nbc) * d.bs, c0 = (blk % d.nbc) * d.bs;
+    const uint8_t* prev = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const int nc = 2 * d.sw + d.bs;
+    const int total = nc * nc;
+    unsigned long long best = ~0ull;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int ci = idx / nc, ri = idx - ci * nc;        // column offset is the outer loop
+        const int top = r0 + ri - d.sw, left = c0 + ci - d.sw;
+        if (top < 0 || left < 0 || top + d.bs > d.H || left + d.bs > d.W) continue;
+        const uint8_t* cand = cur + (long long)top * d.pitch + left;
+        unsigned long long cost = 0;
+        for (int y = 0; y < d.bs; ++y) {
+            const uint8_t* a = prev + (long long)y * d.pitch;
+            const uint8_t* c = cand + (long long)y * d.pitch;
+            unsigned row = 0;
+            if (d.pnorm == 0) {
+                for (int x = 0; x < d.bs; ++x) row += (unsigned)abs((int)a[x] - (int)c[x]);
+                cost += row;
+            } else {
+                unsigned long long r64 = 0;
+                for (int x = 0; x < d.bs; ++x) { int df = (int)a[x] - (int)c[x]; r64 += (unsigned)(df * df); }
+                cost += r64;
+            }
+        }
+        best = u64min(best, (cost << 24) | (unsigned)idx);   // first minimum in scan order
+    }
+    for (int m = 32; m > 0; m >>= 1) best = u64min(best, shfl_xor_u64(best, m));
+    if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = u64min(u64min(wave_best[0], wave_best[1]), u64min(wave_best[2], wave_best[3]));
+        const int idx = (int)(best & 0xFFFFFF);
+        const int ci = idx / nc, ri = idx - ci * nc;
+        int32_t* o = d.mf + ((long long)pair * nblk + blk) * 2;
+        o[0] = ci - d.sw;
+        o[1] = ri - d.sw;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// walk searches: G lanes cooperate on one block
+// ---------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ unsigned long long group_cost(const uint8_t* anchor, const uint8_t* cand,
+                                                         int pitch, int bs, int pnorm, int lig)
+{
+    unsigned long long acc = 0;
+    const int n = bs * bs;
+    int y = lig / bs, x = lig - y * bs;
+    const int dy = G / bs, dx = G - dy * bs;
+    for (int p = lig; p < n; p += G) {
+        const int df = (int)anchor[y * pitch + x] - (int)cand[y * pitch + x];
+        acc += pnorm ? (unsigned)(df * df) : (unsigned)abs(df);
+        y += dy; x += dx;
+        if (x >= bs) { x -= bs; ++y; }
+    }
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) acc += shfl_xor_u64(acc, m);
+    return acc;
+}
+
+__constant__ int c_ldsp[9][2] = { {0,0},{2,0},{1,1},{0,2},{-1,1},{-2,0},{-1,-1},{0,-2},{1,-1} };
+__constant__ int c_sdsp[5][2] = { {0,0},{1,0},{0,1},{-1,0},{0,-1} };
+
+__device__ __forceinline__ int clamp_ref(int v, int hi)   // min(max(v, 0), hi), bbme.py:503-504
+{
+    const int t = v > 0 ? v : 0;
+    return t < hi ? t : hi;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_walk(Dev d)
+{
+    const int nblk = d.nbr * d.nbc;
+    const long long total = (long long)nblk * d.pairs;
+    const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lig = threadIdx.x % G;
+    const bool active = gid < total;
+    const long long g = active ? gid : 0;
+    const int pair = (int)(g / nblk), blk = (int)(g % nblk);
+    const int r0 = (blk / d.nbc) * d.bs, c0 = (blk % d.nbc) * d.bs;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const uint8_t* anchor = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+    const int bs = d.bs, H = d.H, W = d.W, pitch = d.pitch, pnorm = d.pnorm;
+    const unsigned long long INF = ~0ull;
+    const int cap = 2 * (H + W) + 64;       // walks strictly decrease the cost; this is a guard
+    bool overrun = false;
+    int out0 = 0, out1 = 0;
+
+#define COST_AT(rr, cc) group_cost<G>(anchor, cur + (long long)(rr) * pitch + (cc), pitch, bs, pnorm, lig)
+#define INSIDE(rr, cc) ((rr) >= 0 && (cc) >= 0 && (rr) + bs <= H && (cc) + bs <= W)
+
+    if (d.procedure == GME_SEARCH_DIAMOND) {           // bbme.py:436-534
+        const int maxr = H - bs - 1, maxc = W - bs - 1;
+        int pr = r0, pc = c0, br = r0, bc = c0;
+        bool done = !active;
+        int it = 0;
+        while (__any(!done)) {
+            unsigned long long best = INF;
+            int nr = pr, nc = pc;
+            for (int k = 0; k < 9; ++k) {
+                const int rr = clamp_ref(pr + c_ldsp[k][0], maxr), cc = clamp_ref(pc + c_ldsp[k][1], maxc);
+                const unsigned long long c = COST_AT(rr, cc);
+                if (c < best) { best = c; nr = rr; nc = cc; }
+            }
+            if (!done) {
+                done = (nr == pr && nc == pc);
+                pr = nr; pc = nc;
+            }
+            if (++it > cap) { overrun = true; break; }
+        }
+        unsigned long long best = INF;
+        br = pr; bc = pc;
+        for (int k = 0; k < 5; ++k) {                  // offsets applied swapped, bbme.py:518-521
+            const int rr = clamp_ref(pr + c_sdsp[k][1], maxr), cc = clamp_ref(pc + c_sdsp[k][0], maxc);
+            const unsigned long long c = COST_AT(rr, cc);
+            if (c < best) { best = c; br = rr; bc = cc; }
+        }
+        out1 = br - r0; out0 = bc - c0;
+    } else if (d.procedure == GME_SEARCH_THREESTEP) {  // bbme.py:182-341
+        const int n = 2 * d.sw + bs;
+        const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };
+        int drow = 0, dcol = 0, trow = 0, tcol = 0;
+        int org_r = r0, org_c = c0;
+        for (int s = 0; s < 3; ++s) {
+            const int st = steps[s];
+            unsigned long long best = INF;
+            int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;
+            for (int a = -1; a <= 1; ++a)
+                for (int b = -1; b <= 1; ++b) {
+                    const int wc = a * st, wr = b * st;
+                    const int rr = org_r + wr, cc = org_c + wc;
+                    // every lane of the wave must take part in the shuffles of COST_AT
+                    const bool ok = INSIDE(rr, cc);
+                    const unsigned long long c = COST_AT(ok ? rr : r0, ok ? cc : c0);
+                    if (ok && c < best) { best = c; kr = wr; kc = wc; }
+                }
+            if (s == 0) { drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol; }
+            else {
+                trow = kr; tcol = kc;
+                drow += trow; dcol += tcol;
+                org_r += drow; org_c += dcol;          // bbme.py:300-301 (accumulated again)
+            }
+        }
+        out0 = dcol; out1 = drow;
+    } else {                                           // 2-D log, bbme.py:344-433
+        int br = 0, bc = 0, pr = r0, pc = c0;
+        int step = active ? d.sw : 0;
+        int it = 0;
+        while (__any(step > 1)) {
+            const bool cross = step > 2;
+            unsigned long long best = INF;
+            int nr = br, nc = bc;
+            for (int k = 0; k < 9; ++k) {
+                int rr, cc;
+                if (cross) {
+                    if (k >= 5) break;
+                    rr = pr + (k == 1 ? step : k == 2 ? -step : 0);
+                    cc = pc + (k == 3 ? step : k == 4 ? -step : 0);
+                } else {
+                    rr = pr + (k / 3 - 1) * 2;
+                    cc = pc + (k % 3 - 1) * 2;
+                }
+                const bool ok = INSIDE(rr, cc);
+                const unsigned long long c = COST_AT(ok ? rr : r0, ok ? cc : c0);
+                if (ok && c < best) { best = c; nr = rr; nc = cc; }
+            }
+            if (step > 1) {
+                br = nr; bc = nc;
+                if ((br == pr && bc == pc) || step == 2) step /= 2;
+                pr = br; pc = bc;
+            }
+            if (++it > cap) { overrun = true; break; }
+        }
+        out1 = br - r0; out0 = bc - c0;
+    }
+#undef COST_AT
+#undef INSIDE
+    if (overrun && lig == 0) atomicExch(d.status, 1);
+    if (active && lig == 0) {
+        int32_t* o = d.mf + gid * 2;
+        o[0] = out0; o[1] = out1;
+    }
+}
+
+}  // namespace
+
+// the `break` inside the 2-D log candidate loop is wave-divergent only between groups
+// whose `cross` differs; COST_AT shuffles stay inside a group (width G), and every lane
+// of a group shares `cross`, so no shuffle partner is ever missing.
+
+int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
+{
+    GME_REQUIRE(procedure >= 0 && procedure <= 3, GME_ERR_ARG, "searching_procedure %d out of range (bbme.py:27)", procedure);
+    GME_REQUIRE(pnorm == 0 || pnorm == 1, GME_ERR_ARG, "pnorm_distance %d out of range (bbme.py:60)", pnorm);
+    GME_REQUIRE(bs >= 1 && H >= 1 && W >= 1, GME_ERR_ARG, "bad geometry H=%d W=%d bs=%d", H, W, bs);
+    GME_REQUIRE(bs <= 4096, GME_ERR_ARG, "block_size %d too large", bs);
+    const double worst = (double)bs * bs * (pnorm ? 65025.0 : 255.0);
+    GME_REQUIRE(worst < 16777216.0, GME_ERR_INEXACT,
+                "block_size %d with %s leaves float32's exact-integer range (bbme.py:61-64): "
+                "the reference's own result depends on NumPy's summation order there",
+                bs, pnorm ? "MSE" : "MAE");
+    if (procedure == GME_SEARCH_EXHAUSTIVE) {
+        GME_REQUIRE(sw >= 0 && 2 * sw + bs < 4096, GME_ERR_ARG, "search_window %d out of range", sw);
+    }
+    if (procedure == GME_SEARCH_DIAMOND && H / bs > 0 && W / bs > 0) {
+        GME_REQUIRE(H - bs - 1 >= 0 && W - bs - 1 >= 0, GME_ERR_GEOMETRY,
+                    "diamond search needs H > bs and W > bs (bbme.py:503-505 slices an empty block otherwise)");
+    }
+    return GME_OK;
+}
+
+int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
+
+int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
+{
+    int rc = bbme_check_args(job.H, job.W, job.bs, job.sw, job.procedure, job.pnorm);
+    if (rc != GME_OK) return rc;
+    Dev d;
+    d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
+    d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch;
+    d.bs = job.bs; d.sw = job.sw; d.pnorm = job.pnorm; d.procedure = job.procedure;
+    d.nbr = job.H / job.bs; d.nbc = job.W / job.bs;
+    d.mf = job.mf;
+    const long long nblk = (long long)d.nbr * d.nbc;
+    if (nblk == 0 || job.pairs == 0) return GME_OK;
+    GME_REQUIRE(nblk * job.pairs < (1ll << 31) / 64, GME_ERR_ARG, "too many blocks in one launch");
+
+    bool handled = false;
+    rc = launch_bbme_fast(ctx, job, &handled);
+    if (rc != GME_OK || handled) return rc;
+
+    d.status = ctx->status;
+
+    if (job.procedure == GME_SEARCH_EXHAUSTIVE) {
+        hipLaunchKernelGGL(k_exh_generic, dim3((unsigned)(nblk * job.pairs)), dim3(256), 0, ctx->stream, d);
+    } else {
+        const int px = job.bs * job.bs;
+        const int G = px <= 4 ? 1 : px <= 16 ? 4 : px <= 64 ? 16 : 64;
+        const long long threads = nblk * job.pairs * G;
+        const unsigned grid = (unsigned)((threads + 255) / 256);
+        switch (G) {
+        case 1: hipLaunchKernelGGL(k_walk<1>, dim3(grid), dim3(256), 0, ctx->stream, d); break;
+        case 4: hipLaunchKernelGGL(k_walk<4>, dim3(grid), dim3(256), 0, ctx->stream, d); break;
+        case 16: hipLaunchKernelGGL(k_walk<16>, dim3(grid), dim3(256), 0, ctx->stream, d); break;
+        default: hipLaunchKernelGGL(k_walk<64>, dim3(grid), dim3(256), 0, ctx->stream, d); break;
+        }
+    }
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}

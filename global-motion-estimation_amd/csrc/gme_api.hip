@@ -1,0 +1,697 @@
+// C ABI of libgme_hip.so (include/gme_hip.h): contexts, sequences, host<->device
+// plumbing around the kernels in bbme_*.hip, gme_kernels.hip and synth_kernels.hip.
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+
+#include "gme_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void gme_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gme_last_error(void) { return g_err; }
+
+extern "C" int gme_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { gme_set_error("hipGetDeviceCount failed (no HIP device?)"); return 0; }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" gme_ctx* gme_create(int device_id)
+{
+    int n = gme_device_count();
+    if (device_id < 0 || device_id >= n) {
+        gme_set_error("gme_create: device %d not available (%d HIP devices visible)", device_id, n);
+        return nullptr;
+    }
+    gme_ctx* ctx = new (std::nothrow) gme_ctx();
+    if (!ctx) return nullptr;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc((void**)&ctx->status, 256) != hipSuccess || hipMemset(ctx->status, 0, 256) != hipSuccess) {
+        gme_set_error("gme_create: HIP initialisation failed on device %d: %s", device_id,
+                      hipGetErrorString(hipGetLastError()));
+        delete ctx;
+        return nullptr;
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        gme_set_error("gme_create: device %d is %s; this library carries gfx950 code only", device_id,
+                      ctx->prop.gcnArchName);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void gme_destroy(gme_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->status) hipFree(ctx->status);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int ctx_enter(gme_ctx* ctx)
+{
+    GME_REQUIRE(ctx != nullptr, GME_ERR_ARG, "null context");
+    GME_HIP_TRY(hipSetDevice(ctx->device));
+    return GME_OK;
+}
+
+// wait for the stream and report a tripped in-kernel guard
+static int ctx_finish(gme_ctx* ctx)
+{
+    int st = 0;
+    GME_HIP_TRY(hipMemcpyAsync(&st, ctx->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (st != 0) {
+        hipMemsetAsync(ctx->status, 0, sizeof(int), ctx->stream);
+        gme_set_error("a search walk exceeded its iteration guard (internal error)");
+        return GME_ERR_STATE;
+    }
+    return GME_OK;
+}
+
+extern "C" int gme_sync(gme_ctx* ctx)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    return ctx_finish(ctx);
+}
+
+extern "C" void* gme_stream(gme_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int gme_device_info(gme_ctx* ctx, char* name, int name_len, int* cu_count, int* clock_khz)
+{
+    GME_REQUIRE(ctx != nullptr, GME_ERR_ARG, "null context");
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = ctx->prop.clockRate;
+    return GME_OK;
+}
+
+extern "C" int gme_timer_start(gme_ctx* ctx)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return GME_OK;
+}
+
+extern "C" int gme_timer_stop(gme_ctx* ctx, float* elapsed_ms)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    GME_HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    GME_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return GME_OK;
+}
+
+int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        const size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+        if (hipMalloc(&ctx->scratch, want) != hipSuccess) {
+            gme_set_error("out of device memory (%zu bytes of scratch)", want);
+            return GME_ERR_NOMEM;
+        }
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return GME_OK;
+}
+
+int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->pinned_bytes) {
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) {
+            gme_set_error("out of pinned host memory (%zu bytes)", bytes);
+            return GME_ERR_NOMEM;
+        }
+        ctx->pinned_bytes = bytes;
+    }
+    *out = ctx->pinned;
+    return GME_OK;
+}
+
+int plane_alloc(Plane* p, int count, int H, int W)
+{
+    p->H = H; p->W = W; p->count = count;
+    p->pitch = round_up(W, 64);
+    p->stride = (int64_t)round_up(p->pitch * H, 256);
+    p->ptr = nullptr;
+    if (count == 0 || H == 0 || W == 0) return GME_OK;
+    // one guard row behind the stack: dword loads near the last row never leave the allocation
+    if (hipMalloc((void**)&p->ptr, p->bytes() + p->pitch) != hipSuccess) {
+        gme_set_error("out of device memory (%zu bytes of frames)", p->bytes());
+        return GME_ERR_NOMEM;
+    }
+    GME_HIP_TRY(hipMemset(p->ptr, 0, p->bytes() + p->pitch));
+    return GME_OK;
+}
+
+void plane_free(Plane* p)
+{
+    if (p->ptr) hipFree(p->ptr);
+    p->ptr = nullptr;
+}
+
+// carve `n` sub-buffers out of the context scratch, 256-byte aligned
+struct Carver {
+    uint8_t* base = nullptr;
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
+};
+
+// ---------------------------------------------------------------------------
+// single-pair calls on host buffers
+// ---------------------------------------------------------------------------
+extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int H, int W, int stride,
+                           int block_size, int search_window, int procedure, int pnorm, int32_t* mf_out)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(prev && cur && mf_out, GME_ERR_ARG, "gme_bbme_u8: null pointer");
+    GME_REQUIRE(H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_bbme_u8: bad shape H=%d W=%d stride=%d", H, W, stride);
+    GME_REQUIRE(block_size >= 1, GME_ERR_ARG, "gme_bbme_u8: block_size %d", block_size);
+    rc = bbme_check_args(H, W, block_size, search_window, procedure, pnorm);
+    if (rc) return rc;
+    const int h = H / block_size, w = W / block_size;
+    if (h == 0 || w == 0) return GME_OK;
+    const int pitch = round_up(W, 64);
+    const size_t plane = (size_t)round_up(pitch * H, 256);
+    Carver c;
+    const size_t o_prev = c.take(plane + pitch), o_cur = c.take(plane + pitch);
+    const size_t o_mf = c.take((size_t)h * w * 2 * sizeof(int32_t));
+    void* base = nullptr;
+    rc = ctx_scratch(ctx, c.off, &base);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)base;
+    GME_HIP_TRY(hipMemsetAsync(b + o_prev, 0, o_mf - o_prev, ctx->stream));
+    GME_HIP_TRY(hipMemcpy2DAsync(b + o_prev, pitch, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    GME_HIP_TRY(hipMemcpy2DAsync(b + o_cur, pitch, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    BbmeJob job;
+    job.prev = b + o_prev; job.cur = b + o_cur; job.plane_stride = 0; job.pairs = 1;
+    job.H = H; job.W = W; job.pitch = pitch;
+    job.bs = block_size; job.sw = search_window; job.procedure = procedure; job.pnorm = pnorm;
+    job.mf = (int32_t*)(b + o_mf); job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+    rc = launch_bbme(ctx, job);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpyAsync(mf_out, b + o_mf, (size_t)h * w * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+extern "C" int gme_pyrdown_u8(gme_ctx* ctx, const uint8_t* src, int H, int W, int stride, uint8_t* dst)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(src && dst && H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_pyrdown_u8: bad arguments");
+    Plane s, d;
+    s.H = H; s.W = W; s.pitch = round_up(W, 64); s.stride = round_up(s.pitch * H, 256); s.count = 1;
+    d.H = (H + 1) / 2; d.W = (W + 1) / 2; d.pitch = round_up(d.W, 64); d.stride = round_up(d.pitch * d.H, 256); d.count = 1;
+    Carver c;
+    const size_t o_s = c.take(s.stride), o_d = c.take(d.stride);
+    void* base = nullptr;
+    rc = ctx_scratch(ctx, c.off, &base);
+    if (rc) return rc;
+    s.ptr = (uint8_t*)base + o_s; d.ptr = (uint8_t*)base + o_d;
+    GME_HIP_TRY(hipMemcpy2DAsync(s.ptr, s.pitch, src, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_pyrdown(ctx, s, d);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpy2DAsync(dst, d.W, d.ptr, d.pitch, d.W, d.H, hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+extern "C" int gme_affine_field(gme_ctx* ctx, const double params[6], int h, int w, int16_t* mf_out)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(params && mf_out && h >= 0 && w >= 0, GME_ERR_ARG, "gme_affine_field: bad arguments");
+    if (h == 0 || w == 0) return GME_OK;
+    Carver c;
+    const size_t o_p = c.take(6 * sizeof(double)), o_f = c.take((size_t)h * w * 2 * sizeof(int16_t));
+    void* base = nullptr;
+    rc = ctx_scratch(ctx, c.off, &base);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)base;
+    GME_HIP_TRY(hipMemcpyAsync(b + o_p, params, 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_affine_field(ctx, (const double*)(b + o_p), 1, h, w, (int16_t*)(b + o_f));
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpyAsync(mf_out, b + o_f, (size_t)h * w * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+extern "C" int gme_compensate_u8(gme_ctx* ctx, const uint8_t* frame, int H, int W, int stride, const int32_t* mf,
+                                 int h, int w, uint8_t* out)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(frame && mf && out && H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_compensate_u8: bad arguments");
+    GME_REQUIRE(h > 0 && w > 0 && h <= H, GME_ERR_ARG,
+                "gme_compensate_u8: field of %d x %d blocks on a %d-row frame (motion.py:303 divides H by it)", h, w, H);
+    const int pitch = round_up(W, 64);
+    const size_t plane = (size_t)round_up(pitch * H, 256);
+    Carver c;
+    const size_t o_f = c.take(plane), o_o = c.take(plane), o_m = c.take((size_t)h * w * 2 * sizeof(int32_t));
+    void* base = nullptr;
+    rc = ctx_scratch(ctx, c.off, &base);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)base;
+    GME_HIP_TRY(hipMemcpy2DAsync(b + o_f, pitch, frame, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    GME_HIP_TRY(hipMemcpyAsync(b + o_m, mf, (size_t)h * w * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_compensate(ctx, b + o_f, 0, 1, H, W, pitch, (const int32_t*)(b + o_m), nullptr, h, w, b + o_o, 0, pitch,
+                           nullptr, 0, nullptr);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpy2DAsync(out, W, b + o_o, pitch, W, H, hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+extern "C" int gme_sse_u8(gme_ctx* ctx, const uint8_t* a, const uint8_t* b_, int H, int W, int stride_a, int stride_b,
+                          int64_t* sse_out)
+{
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(a && b_ && sse_out && H > 0 && W > 0 && stride_a >= W && stride_b >= W, GME_ERR_ARG,
+                "gme_sse_u8: bad arguments");
+    const int pitch = round_up(W, 64);
+    const size_t plane = (size_t)round_up(pitch * H, 256);
+    Carver c;
+    const size_t o_a = c.take(plane), o_b = c.take(plane), o_s = c.take(sizeof(unsigned long long));
+    void* base = nullptr;
+    rc = ctx_scratch(ctx, c.off, &base);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)base;
+    GME_HIP_TRY(hipMemcpy2DAsync(b + o_a, pitch, a, stride_a, W, H, hipMemcpyHostToDevice, ctx->stream));
+    GME_HIP_TRY(hipMemcpy2DAsync(b + o_b, pitch, b_, stride_b, W, H, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_sse(ctx, b + o_a, 0, pitch, b + o_b, 0, pitch, 1, H, W, (unsigned long long*)(b + o_s));
+    if (rc) return rc;
+    unsigned long long v = 0;
+    GME_HIP_TRY(hipMemcpyAsync(&v, b + o_s, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    rc = ctx_finish(ctx);
+    *sse_out = (int64_t)v;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// sequences
+// ---------------------------------------------------------------------------
+extern "C" gme_seq* gme_seq_create(gme_ctx* ctx, int n_frames, int H, int W)
+{
+    if (ctx_enter(ctx)) return nullptr;
+    if (n_frames < 1 || H < 1 || W < 1) { gme_set_error("gme_seq_create: bad shape"); return nullptr; }
+    gme_seq* s = new (std::nothrow) gme_seq();
+    if (!s) return nullptr;
+    s->ctx = ctx; s->N = n_frames; s->H = H; s->W = W;
+    if (plane_alloc(&s->level[2], n_frames, H, W) != GME_OK) { delete s; return nullptr; }
+    return s;
+}
+
+static void free_fit(FitLevelBuf& f)
+{
+    if (f.gt) hipFree(f.gt);
+    if (f.model) hipFree(f.model);
+    if (f.mask) hipFree(f.mask);
+    if (f.diff) hipFree(f.diff);
+    if (f.thr) hipFree(f.thr);
+    if (f.sums) hipFree(f.sums);
+    f = FitLevelBuf();
+}
+
+extern "C" void gme_seq_destroy(gme_seq* s)
+{
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    for (int l = 0; l < 3; ++l) { plane_free(&s->level[l]); free_fit(s->fit[l]); }
+    s->fit_mv.gt = nullptr;
+    free_fit(s->fit_mv);
+    if (s->mv_params) hipFree(s->mv_params);
+    plane_free(&s->comp);
+    if (s->mv) hipFree(s->mv);
+    if (s->sqbox) hipFree(s->sqbox);
+    if (s->params0) hipFree(s->params0);
+    if (s->params_in) hipFree(s->params_in);
+    if (s->sse) hipFree(s->sse);
+    if (s->comp_params) hipFree(s->comp_params);
+    if (s->synth_canvas) hipFree(s->synth_canvas);
+    delete s;
+}
+
+extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* frames, int row_stride,
+                              int64_t frame_stride)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
+                "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
+    const Plane& p = s->level[2];
+    for (int i = 0; i < count; ++i)
+        GME_HIP_TRY(hipMemcpy2DAsync(p.at(first + i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
+                                     hipMemcpyHostToDevice, s->ctx->stream));
+    s->pyramids_valid = false;
+    GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // the host buffer may be reused on return
+    return GME_OK;
+}
+
+extern "C" int gme_seq_synth(gme_seq* s, uint64_t seed, int t0)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    if (!s->synth_canvas) {
+        if (hipMalloc((void**)&s->synth_canvas, (size_t)2048 * 4096) != hipSuccess) {
+            gme_set_error("out of device memory (synthetic canvas)");
+            return GME_ERR_NOMEM;
+        }
+        s->synth_valid = false;
+    }
+    if (!s->synth_valid || s->synth_seed != seed) {
+        rc = launch_synth_canvas(s->ctx, seed, s->synth_canvas);
+        if (rc) return rc;
+        s->synth_seed = seed; s->synth_valid = true;
+    }
+    s->pyramids_valid = false;
+    return launch_synth_frames(s->ctx, seed, t0, s->synth_canvas, s->level[2]);
+}
+
+extern "C" int gme_seq_read_frame(gme_seq* s, int level, int index, uint8_t* out)
+{
+    GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_frame: null pointer");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    GME_REQUIRE(level >= 0 && level <= 2 && index >= 0 && index < s->N, GME_ERR_ARG, "gme_seq_read_frame: bad index");
+    GME_REQUIRE(level == 2 || s->pyramids_valid, GME_ERR_STATE, "pyramid levels exist only after gme_seq_gme_begin");
+    const Plane& p = s->level[level];
+    GME_HIP_TRY(hipMemcpy2DAsync(out, p.W, p.at(index), p.pitch, p.W, p.H, hipMemcpyDeviceToHost, s->ctx->stream));
+    return ctx_finish(s->ctx);
+}
+
+template <typename T>
+static int ensure(T** ptr, size_t* have, size_t want_bytes)
+{
+    if (*ptr && *have >= want_bytes) return GME_OK;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr; *have = 0;
+    if (want_bytes == 0) return GME_OK;
+    if (hipMalloc((void**)ptr, want_bytes) != hipSuccess) {
+        gme_set_error("out of device memory (%zu bytes)", want_bytes);
+        return GME_ERR_NOMEM;
+    }
+    *have = want_bytes;
+    return GME_OK;
+}
+
+extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, int pnorm)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
+    GME_REQUIRE(bs >= 1, GME_ERR_ARG, "block_size %d", bs);
+    rc = bbme_check_args(s->H, s->W, bs, sw, procedure, pnorm);
+    if (rc) return rc;
+    const int pairs = s->N - fd, h = s->H / bs, w = s->W / bs;
+    rc = ensure(&s->mv, &s->mv_bytes, (size_t)pairs * h * w * 2 * sizeof(int32_t));
+    if (rc) return rc;
+    s->mv_h = h; s->mv_w = w; s->mv_pairs = pairs;
+    const Plane& p = s->level[2];
+    BbmeJob job;
+    job.prev = p.at(0); job.cur = p.at(fd); job.plane_stride = p.stride; job.pairs = pairs;
+    job.H = s->H; job.W = s->W; job.pitch = p.pitch;
+    job.bs = bs; job.sw = sw; job.procedure = procedure; job.pnorm = pnorm;
+    job.mf = s->mv; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+    return launch_bbme(s->ctx, job);
+}
+
+extern "C" int gme_seq_read_mv(gme_seq* s, int first_pair, int count, int32_t* mf_out)
+{
+    GME_REQUIRE(s != nullptr && mf_out != nullptr, GME_ERR_ARG, "gme_seq_read_mv: null pointer");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    GME_REQUIRE(s->mv != nullptr, GME_ERR_STATE, "gme_seq_read_mv before gme_seq_bbme");
+    GME_REQUIRE(first_pair >= 0 && count >= 0 && first_pair + count <= s->mv_pairs, GME_ERR_ARG,
+                "gme_seq_read_mv: pairs [%d, %d) outside [0, %d)", first_pair, first_pair + count, s->mv_pairs);
+    const size_t per = (size_t)s->mv_h * s->mv_w * 2;
+    GME_HIP_TRY(hipMemcpyAsync(mf_out, s->mv + per * first_pair, per * count * sizeof(int32_t), hipMemcpyDeviceToHost,
+                               s->ctx->stream));
+    return ctx_finish(s->ctx);
+}
+
+static int alloc_fit(FitLevelBuf& f, int pairs, int h, int w, bool full)
+{
+    free_fit(f);
+    f.h = h; f.w = w;
+    const size_t n = (size_t)pairs * h * w;
+    if (n == 0) return GME_OK;
+    bool ok = hipMalloc((void**)&f.gt, n * 2 * sizeof(int32_t)) == hipSuccess;
+    if (full) {
+        ok = ok && hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&f.mask, n) == hipSuccess;
+        ok = ok && hipMalloc((void**)&f.diff, n * sizeof(int32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&f.thr, (size_t)pairs * sizeof(int32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&f.sums, (size_t)pairs * 15 * sizeof(double)) == hipSuccess;
+    }
+    if (!ok) { gme_set_error("out of device memory (GME level buffers)"); return GME_ERR_NOMEM; }
+    return GME_OK;
+}
+
+extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, float* params0_out)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    gme_ctx* ctx = s->ctx;
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
+    GME_REQUIRE(bbme_bs >= 1, GME_ERR_ARG, "block_size %d", bbme_bs);
+    const int pairs = s->N - fd;
+    // pyramids (utils.py:34-51): level 1 = pyrDown(level 2), level 0 = pyrDown(level 1)
+    for (int l = 1; l >= 0; --l) {
+        const Plane& src = s->level[l + 1];
+        if (!s->level[l].ptr) {
+            rc = plane_alloc(&s->level[l], s->N, (src.H + 1) / 2, (src.W + 1) / 2);
+            if (rc) return rc;
+        }
+    }
+    // argument checks for the three BBME runs before anything is launched
+    rc = bbme_check_args(s->level[0].H, s->level[0].W, 2, 2, GME_SEARCH_DIAMOND, GME_NORM_MSE);
+    if (rc) return rc;
+    for (int l = 1; l <= 2; ++l) {
+        rc = bbme_check_args(s->level[l].H, s->level[l].W, bbme_bs, sw, procedure, GME_NORM_MSE);
+        if (rc) return rc;
+    }
+    if (!s->pyramids_valid) {
+        for (int l = 1; l >= 0; --l) {
+            rc = launch_pyrdown(ctx, s->level[l + 1], s->level[l]);
+            if (rc) return rc;
+        }
+        s->pyramids_valid = true;
+    }
+    if (s->gme_alloc_pairs != (size_t)pairs || s->gme_bs != bbme_bs) {
+        rc = alloc_fit(s->fit[0], pairs, s->level[0].H / 2, s->level[0].W / 2, false);
+        if (rc) return rc;
+        for (int l = 1; l <= 2; ++l) {
+            rc = alloc_fit(s->fit[l], pairs, s->level[l].H / bbme_bs, s->level[l].W / bbme_bs, true);
+            if (rc) return rc;
+        }
+        if (s->params0) hipFree(s->params0);
+        if (s->params_in) hipFree(s->params_in);
+        s->params0 = nullptr; s->params_in = nullptr;
+        if (hipMalloc((void**)&s->params0, (size_t)pairs * 6 * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&s->params_in, (size_t)pairs * 6 * sizeof(double)) != hipSuccess) {
+            gme_set_error("out of device memory (parameters)");
+            return GME_ERR_NOMEM;
+        }
+        s->gme_alloc_pairs = pairs;
+    }
+    s->gme_fd = fd; s->gme_bs = bbme_bs; s->gme_pairs = pairs;
+    // dense field on the coarsest level: bs 2, diamond, MSE (motion.py:27-29; bbme.py:18 default norm)
+    for (int l = 0; l <= 2; ++l) {
+        const Plane& p = s->level[l];
+        BbmeJob job;
+        job.prev = p.at(0); job.cur = p.at(fd); job.plane_stride = p.stride; job.pairs = pairs;
+        job.H = p.H; job.W = p.W; job.pitch = p.pitch;
+        job.bs = l == 0 ? 2 : bbme_bs;
+        job.sw = l == 0 ? 2 : sw;
+        job.procedure = l == 0 ? GME_SEARCH_DIAMOND : procedure;
+        job.pnorm = GME_NORM_MSE;
+        job.mf = s->fit[l].gt; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+        if (s->fit[l].h == 0 || s->fit[l].w == 0) continue;
+        rc = launch_bbme(ctx, job);
+        if (rc) return rc;
+    }
+    GME_REQUIRE(s->fit[0].h > 0 && s->fit[0].w > 0, GME_ERR_GEOMETRY, "frames too small for a dense field");
+    rc = launch_first_params(ctx, s->fit[0].gt, pairs, s->fit[0].h * s->fit[0].w, s->params0);
+    if (rc) return rc;
+    if (params0_out) {
+        GME_HIP_TRY(hipMemcpyAsync(params0_out, s->params0, (size_t)pairs * 6 * sizeof(float), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        return ctx_finish(ctx);
+    }
+    return GME_OK;
+}
+
+static int ensure_fit_mv(gme_seq* s)
+{
+    FitLevelBuf& f = s->fit_mv;
+    if (f.h == s->mv_h && f.w == s->mv_w && s->fit_mv_pairs == s->mv_pairs && f.model) { f.gt = s->mv; return GME_OK; }
+    f.gt = nullptr;                       // borrowed from s->mv, never freed here
+    if (f.model) hipFree(f.model);
+    if (f.mask) hipFree(f.mask);
+    if (f.diff) hipFree(f.diff);
+    if (f.thr) hipFree(f.thr);
+    if (f.sums) hipFree(f.sums);
+    f = FitLevelBuf();
+    f.h = s->mv_h; f.w = s->mv_w;
+    const size_t n = (size_t)s->mv_pairs * f.h * f.w;
+    if (hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&f.mask, n) != hipSuccess ||
+        hipMalloc((void**)&f.diff, n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&f.thr, (size_t)s->mv_pairs * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&f.sums, (size_t)s->mv_pairs * 15 * sizeof(double)) != hipSuccess) {
+        gme_set_error("out of device memory (fit buffers)");
+        return GME_ERR_NOMEM;
+    }
+    f.gt = s->mv;
+    s->fit_mv_pairs = s->mv_pairs;
+    return GME_OK;
+}
+
+extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, double outlier_fraction,
+                               double* sums_out)
+{
+    GME_REQUIRE(s != nullptr && params_in != nullptr && sums_out != nullptr, GME_ERR_ARG, "gme_seq_gme_fit: null pointer");
+    gme_ctx* ctx = s->ctx;
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(level == 1 || level == 2 || level == -1, GME_ERR_ARG, "gme_seq_gme_fit: level %d (1, 2 or -1)", level);
+    int pairs, level_H, level_W;
+    const FitLevelBuf* f;
+    double* dparams;
+    if (level == -1) {
+        GME_REQUIRE(s->mv != nullptr && s->mv_pairs > 0, GME_ERR_STATE, "gme_seq_gme_fit(level -1) before gme_seq_bbme");
+        rc = ensure_fit_mv(s);
+        if (rc) return rc;
+        f = &s->fit_mv; pairs = s->mv_pairs; level_H = s->H; level_W = s->W;
+        size_t have = s->mv_params_bytes;
+        rc = ensure(&s->mv_params, &have, (size_t)pairs * 6 * sizeof(double));
+        s->mv_params_bytes = have;
+        if (rc) return rc;
+        dparams = s->mv_params;
+    } else {
+        GME_REQUIRE(s->gme_pairs > 0 && s->params_in, GME_ERR_STATE, "gme_seq_gme_fit before gme_seq_gme_begin");
+        f = &s->fit[level]; pairs = s->gme_pairs; level_H = s->level[level].H; level_W = s->level[level].W;
+        dparams = s->params_in;
+    }
+    const int n = f->h * f->w;
+    GME_REQUIRE(n > 0, GME_ERR_GEOMETRY, "level %d holds no block (motion.py:243 would index an empty list)", level);
+    // int(0.3 * len), motion.py:242; a negative fraction selects the unmasked fit (motion.py:33-88)
+    const int drop = outlier_fraction < 0 ? -1 : (int)(outlier_fraction * (double)n);
+    GME_REQUIRE(drop <= n, GME_ERR_ARG, "outlier fraction %g out of range", outlier_fraction);
+    GME_HIP_TRY(hipMemcpyAsync(dparams, params_in, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, level_H, level_W, f->model, f->mask, f->diff,
+                          f->thr, f->sums);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* gt, int16_t* model, uint8_t* mask,
+                                      int64_t* threshold)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    gme_ctx* ctx = s->ctx;
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(level >= -1 && level <= 2 && pair >= 0 && pair < (level < 0 ? s->fit_mv_pairs : s->gme_pairs), GME_ERR_ARG,
+                "gme_seq_gme_read_stage: bad index");
+    const FitLevelBuf& f = level < 0 ? s->fit_mv : s->fit[level];
+    const size_t n = (size_t)f.h * f.w;
+    int32_t thr = 0;
+    if (gt && n) GME_HIP_TRY(hipMemcpyAsync(gt, f.gt + n * 2 * pair, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (level != 0) {
+        if (model && n) GME_HIP_TRY(hipMemcpyAsync(model, f.model + n * 2 * pair, n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (mask && n) GME_HIP_TRY(hipMemcpyAsync(mask, f.mask + n * pair, n, hipMemcpyDeviceToHost, ctx->stream));
+        if (threshold) GME_HIP_TRY(hipMemcpyAsync(&thr, f.thr + pair, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    rc = ctx_finish(ctx);
+    if (threshold) *threshold = thr;
+    return rc;
+}
+
+extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* params, int64_t* sse_out)
+{
+    GME_REQUIRE(s != nullptr && params != nullptr, GME_ERR_ARG, "gme_seq_compensate: null pointer");
+    gme_ctx* ctx = s->ctx;
+    int rc = ctx_enter(ctx);
+    if (rc) return rc;
+    GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
+    const int pairs = s->N - fd;
+    GME_REQUIRE(pairs <= 65535, GME_ERR_ARG, "at most 65535 pairs per call");
+    const int h = s->H / bs, w = s->W / bs;
+    GME_REQUIRE(bs >= 1 && h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
+    if (!s->comp.ptr || s->comp.count != pairs) {
+        plane_free(&s->comp);
+        rc = plane_alloc(&s->comp, pairs, s->H, s->W);
+        if (rc) return rc;
+        if (s->sse) hipFree(s->sse);
+        if (s->comp_params) hipFree(s->comp_params);
+        s->sse = nullptr; s->comp_params = nullptr;
+        if (hipMalloc((void**)&s->sse, (size_t)pairs * sizeof(unsigned long long)) != hipSuccess ||
+            hipMalloc((void**)&s->comp_params, (size_t)pairs * 6 * sizeof(double)) != hipSuccess) {
+            gme_set_error("out of device memory");
+            return GME_ERR_NOMEM;
+        }
+    }
+    GME_HIP_TRY(hipMemcpyAsync(s->comp_params, params, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const Plane& p = s->level[2];
+    rc = launch_compensate(ctx, p.at(0), p.stride, pairs, s->H, s->W, p.pitch, nullptr, s->comp_params, h, w, s->comp.ptr,
+                           s->comp.stride, s->comp.pitch, p.at(fd), p.stride, s->sse);
+    if (rc) return rc;
+    if (sse_out) {
+        GME_HIP_TRY(hipMemcpyAsync(sse_out, s->sse, (size_t)pairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        return ctx_finish(ctx);
+    }
+    return GME_OK;
+}
+
+extern "C" int gme_seq_read_compensated(gme_seq* s, int pair, uint8_t* out)
+{
+    GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_compensated: null pointer");
+    int rc = ctx_enter(s->ctx);
+    if (rc) return rc;
+    GME_REQUIRE(s->comp.ptr && pair >= 0 && pair < s->comp.count, GME_ERR_STATE, "gme_seq_read_compensated: no such pair");
+    GME_HIP_TRY(hipMemcpy2DAsync(out, s->W, s->comp.at(pair), s->comp.pitch, s->W, s->H, hipMemcpyDeviceToHost, s->ctx->stream));
+    return ctx_finish(s->ctx);
+}

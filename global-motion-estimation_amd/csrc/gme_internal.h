@@ -1,0 +1,134 @@
+// Internal declarations shared by the translation units of libgme_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gme_hip.h"
+
+void gme_set_error(const char* fmt, ...);
+
+#define GME_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            gme_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                       \
+            return GME_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define GME_REQUIRE(cond, code, ...)       \
+    do {                                   \
+        if (!(cond)) {                     \
+            gme_set_error(__VA_ARGS__);    \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+// An image plane (or a stack of equally sized planes) in HBM.
+// pitch is a multiple of 64 bytes; bytes between W and pitch are zero.
+struct Plane {
+    uint8_t* ptr = nullptr;
+    int H = 0, W = 0, pitch = 0;
+    int64_t stride = 0;   // bytes between consecutive planes of a stack
+    int count = 0;
+    size_t bytes() const { return (size_t)stride * (size_t)count; }
+    uint8_t* at(int i) const { return ptr + (int64_t)i * stride; }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct gme_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    // growable device scratch for the single-pair convenience calls
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // pinned host staging for small read-backs
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    int* status = nullptr;        // device word set by kernels whose safety guards trip
+};
+
+int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);
+int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out);
+int plane_alloc(Plane* p, int count, int H, int W);
+void plane_free(Plane* p);
+
+struct FitLevelBuf {
+    int h = 0, w = 0;             // motion-field shape at this level
+    int32_t* gt = nullptr;        // [P][h][w][2]
+    int16_t* model = nullptr;     // [P][h][w][2]
+    uint8_t* mask = nullptr;      // [P][h][w]
+    int32_t* diff = nullptr;      // [P][h][w] L1 distance gt vs model
+    int32_t* thr = nullptr;       // [P]
+    double* sums = nullptr;       // [P][15]
+};
+
+struct gme_seq {
+    gme_ctx* ctx = nullptr;
+    int N = 0, H = 0, W = 0;
+    Plane level[3];               // level[2] = full resolution, [1], [0] = pyramid
+    bool pyramids_valid = false;
+    // generic BBME result
+    int32_t* mv = nullptr;        // [P][h][w][2]
+    size_t mv_bytes = 0;
+    int mv_h = 0, mv_w = 0, mv_pairs = 0;
+    uint32_t* sqbox = nullptr;    // per-frame table of 16x16 box sums of squares (MSE fast path)
+    size_t sqbox_bytes = 0;
+    // GME state
+    int gme_fd = 0, gme_bs = 0, gme_pairs = 0;
+    FitLevelBuf fit[3];           // fit[0].gt = dense field
+    FitLevelBuf fit_mv;           // stage buffers for fitting `mv` directly (gt not owned)
+    int fit_mv_pairs = 0;
+    double* mv_params = nullptr;  // [P][6] parameters for fit_mv
+    size_t mv_params_bytes = 0;
+    float* params0 = nullptr;     // [P][6]
+    double* params_in = nullptr;  // [P][6]
+    size_t gme_alloc_pairs = 0;
+    // compensation
+    Plane comp;                   // [P] compensated frames
+    double* comp_params = nullptr;       // [P][6]
+    unsigned long long* sse = nullptr;   // [P]
+    uint8_t* synth_canvas = nullptr;
+    uint64_t synth_seed = 0;
+    bool synth_valid = false;
+};
+
+// ---- kernel launchers (bbme_kernels.hip) -----------------------------------
+struct BbmeJob {
+    const uint8_t* prev;          // first "previous" plane
+    const uint8_t* cur;           // first "current" plane
+    int64_t plane_stride;         // bytes between consecutive pairs' planes (same for prev/cur)
+    int pairs;
+    int H, W, pitch;
+    int bs, sw, procedure, pnorm;
+    int32_t* mf;                  // [pairs][H/bs][W/bs][2]
+    const uint32_t* sqbox_cur;    // optional, matches `cur` planes: [pairs][H][pitch] uint32
+    int64_t sqbox_stride;         // elements between consecutive planes
+};
+int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
+int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
+
+// ---- gme_kernels.hip --------------------------------------------------------
+int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst);
+int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0);
+int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params,
+                     int drop_count, int level_H, int level_W, int16_t* model, uint8_t* mask,
+                     int32_t* diff, int32_t* thr, double* sums);
+int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out);
+int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride, int pairs, int H,
+                      int W, int pitch, const int32_t* mf32, const double* params, int h, int w,
+                      uint8_t* out, int64_t out_stride, int out_pitch, const uint8_t* cur,
+                      int64_t cur_stride, unsigned long long* sse);
+int launch_sse(gme_ctx* ctx, const uint8_t* a, int64_t a_stride, int a_pitch, const uint8_t* b,
+               int64_t b_stride, int b_pitch, int pairs, int H, int W, unsigned long long* sse);
+
+// ---- synth_kernels.hip ------------------------------------------------------
+int launch_synth_canvas(gme_ctx* ctx, uint64_t seed, uint8_t* canvas);
+int launch_synth_frames(gme_ctx* ctx, uint64_t seed, int t0, const uint8_t* canvas, const Plane& dst);

@@ -1,0 +1,306 @@
+// Global-motion-estimation kernels for gfx950: pyramid, first parameters, per-level
+// robust fit (model field, outlier mask, normal-equation sums), compensation, SSE.
+//
+// Replaces motion.py:109-341 and utils.py:34-51,100-116 of the reference, except the
+// two 3x3 solves per level (motion.py:262-264,280-282), which stay on the host.
+//
+// Floating point: every float64 operation below is written with the *_rn intrinsics,
+// so no FMA contraction can change a rounding; the sums reproduce the reference's
+// sequential `acc += (product) * w` order bit for bit.
+#include "gme_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// cv2.pyrDown (utils.py:48): 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (s + 128) >> 8
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long src_stride, int sH, int sW,
+                                                  int spitch, uint8_t* dst, long long dst_stride, int dH,
+                                                  int dW, int dpitch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dW || y >= dH) return;
+    const uint8_t* s = src + (long long)blockIdx.z * src_stride;
+    int cx[5], k[5] = { 1, 4, 6, 4, 1 };
+#pragma unroll
+    for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * x + d - 2, sW);
+    int acc = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch;
+        int h = 0;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) h += k[d] * row[cx[d]];
+        acc += k[dy] * h;
+    }
+    dst[(long long)blockIdx.z * dst_stride + (long long)y * dpitch + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// ---------------------------------------------------------------------------
+// motion.compute_first_parameters (motion.py:176-188)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_first_params(const int32_t* dense, int n, float* params0)
+{
+    __shared__ long long part[2][4];
+    const int32_t* mf = dense + (long long)blockIdx.x * n * 2;
+    long long s0 = 0, s1 = 0;
+    for (int k = threadIdx.x; k < n; k += 256) { s0 += mf[2 * k]; s1 += mf[2 * k + 1]; }
+    for (int m = 32; m > 0; m >>= 1) {
+        s0 += ((long long)__shfl_xor((int)(s0 >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)s0, m, 64);
+        s1 += ((long long)__shfl_xor((int)(s1 >> 32), m, 64) << 32) | (unsigned)__shfl_xor((int)s1, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s0 = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        s1 = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        float* o = params0 + (long long)blockIdx.x * 6;
+        o[0] = (float)__ddiv_rn((double)s0, (double)n);      // np.mean -> float64, then float32
+        o[1] = 0.f; o[2] = 0.f;
+        o[3] = (float)__ddiv_rn((double)s1, (double)n);
+        o[4] = 0.f; o[5] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// motion.affine_model / get_motion_field_affine (motion.py:91-105,139-157)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int16_t model_component(double p0, double p1, double p2, int i, int j)
+{
+    // gemv order of the reference's NumPy/OpenBLAS (see oracle/gme_oracle.py affine_field):
+    // (p0 + p2*j) + p1*i, each product and sum rounded separately.
+    const double d = __dadd_rn(__dadd_rn(p0, __dmul_rn(p2, (double)j)), __dmul_rn(p1, (double)i));
+    return (int16_t)(long long)rint(d);      // round-half-even, int16 store wraps
+}
+
+__global__ void __launch_bounds__(256) k_affine_field(const double* params, int h, int w, int16_t* out)
+{
+    const int n = h * w;
+    const double* p = params + (long long)blockIdx.y * 6;
+    int16_t* o = out + (long long)blockIdx.y * n * 2;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int i = k / w, j = k - i * w;
+    o[2 * k] = model_component(p[0], p[1], p[2], i, j);
+    o[2 * k + 1] = model_component(p[3], p[4], p[5], i, j);
+}
+
+// ---------------------------------------------------------------------------
+// motion.best_affine_parameters_robust minus BBME and solve (motion.py:232-279)
+// one workgroup per pair
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h, int w, const double* params,
+                                                    int drop, double wgt, int16_t* model_all,
+                                                    uint8_t* mask_all, int32_t* diff_all, int32_t* thr_all,
+                                                    double* sums_all)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int n = h * w;
+    const int pair = blockIdx.x;
+    const int32_t* gt = gt_all + (long long)pair * n * 2;
+    int16_t* model = model_all + (long long)pair * n * 2;
+    uint8_t* mask = mask_all + (long long)pair * n;
+    int32_t* diff = diff_all + (long long)pair * n;
+    const double* p = params + (long long)pair * 6;
+    const double p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5];
+
+    // model field and L1 difference (motion.py:232-239)
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int i = k / w, j = k - i * w;
+        const int16_t m0 = model_component(p0, p1, p2, i, j), m1 = model_component(p3, p4, p5, i, j);
+        model[2 * k] = m0; model[2 * k + 1] = m1;
+        diff[k] = abs(gt[2 * k] - (int)m0) + abs(gt[2 * k + 1] - (int)m1);
+    }
+    // threshold = sorted(diff)[n - drop], or sorted(diff)[0] when drop == 0 (motion.py:240-243);
+    // drop < 0 asks for the unmasked fit of motion.best_affine_parameters (motion.py:33-88)
+    if (threadIdx.x == 0) { sel_prefix = drop < 0 ? 0x7FFFFFFFu : 0u; sel_rank = drop <= 0 ? 0 : (unsigned)(n - drop); }
+    __syncthreads();
+    for (int shift = drop < 0 ? -1 : 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned prefix = sel_prefix;
+        const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const unsigned v = (unsigned)diff[k];
+            if ((v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned rank = sel_rank, cum = 0;
+            int b = 0;
+            for (; b < 255; ++b) {
+                if (rank < cum + hist[b]) break;
+                cum += hist[b];
+            }
+            sel_rank = rank - cum;
+            sel_prefix = prefix | ((unsigned)b << shift);
+        }
+        __syncthreads();
+    }
+    const int thr = (int)sel_prefix;
+    for (int k = threadIdx.x; k < n; k += 256) mask[k] = diff[k] > thr;      // strict, motion.py:244
+    if (threadIdx.x == 0) thr_all[pair] = thr;
+    __syncthreads();
+
+    // sequential float64 sums over inliers in row-major order (motion.py:248-261,266-279);
+    // twelve independent chains, one per lane: F00 F01 F02 F11 F12 F22 | Sx0..2 | Sy0..2
+    if (threadIdx.x < 12) {
+        const int c = threadIdx.x;
+        const int fa[6] = { 0, 0, 0, 1, 1, 2 }, fb[6] = { 0, 1, 2, 1, 2, 2 };
+        const int a = c < 6 ? fa[c] : (c - 6) % 3;
+        const int b = c < 6 ? fb[c] : -1;
+        const int ch = c < 9 ? 0 : 1;
+        double acc = 0.0;
+        int k = 0;
+        for (int i = 0; i < h; ++i) {
+            const double x = (double)(i * 4);                 // literal 4, motion.py:254
+            for (int j = 0; j < w; ++j, ++k) {
+                if (mask[k]) continue;
+                const double y = (double)(j * 4);
+                const double va = a == 0 ? 1.0 : (a == 1 ? x : y);
+                const double vb = b < 0 ? (double)gt[2 * k + ch] : (b == 0 ? 1.0 : (b == 1 ? x : y));
+                acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(va, vb), wgt));
+            }
+        }
+        double* s = sums_all + (long long)pair * 15;
+        if (c < 6) { s[fa[c] * 3 + fb[c]] = acc; s[fb[c] * 3 + fa[c]] = acc; }
+        else s[9 + (c - 6)] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// motion.compensate_frame (motion.py:289-321) fused with the squared error against
+// `cur` (utils.py:109).  The field is either given (mf32) or evaluated from the affine
+// parameters per block (results.py:52-54).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compensate(const uint8_t* frames, long long frame_stride, int H, int W,
+                                                     int pitch, const int32_t* mf32, const double* params, int h,
+                                                     int w, uint8_t* out, long long out_stride, int out_pitch,
+                                                     const uint8_t* cur, long long cur_stride,
+                                                     unsigned long long* sse)
+{
+    const int pair = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint8_t* f = frames + (long long)pair * frame_stride;
+    unsigned long long err = 0;
+    if (x < W && y < H) {
+        const int bs = H / h;                           // height only, motion.py:303
+        const int i = y / bs, j = x / bs;
+        uint8_t v = f[(long long)y * pitch + x];
+        if (i < h && j < w) {
+            int d0, d1;
+            if (mf32) {
+                const int32_t* m = mf32 + (((long long)pair * h + i) * w + j) * 2;
+                d0 = m[0]; d1 = m[1];
+            } else {
+                const double* p = params + (long long)pair * 6;
+                d0 = model_component(p[0], p[1], p[2], i, j);
+                d1 = model_component(p[3], p[4], p[5], i, j);
+            }
+            const long long sy = (long long)y - d1, sx = (long long)x - d0;
+            if (sy >= 0 && sx >= 0 && sy < H && sx < W) v = f[sy * pitch + sx];
+        }
+        out[(long long)pair * out_stride + (long long)y * out_pitch + x] = v;
+        if (cur) {
+            const int df = (int)cur[(long long)pair * cur_stride + (long long)y * pitch + x] - (int)v;
+            err = (unsigned)(df * df);
+        }
+    }
+    if (sse) {
+        for (int m = 32; m > 0; m >>= 1) err += (unsigned long long)__shfl_xor((int)err, m, 64);
+        if ((threadIdx.x & 63) == 0 && err) atomicAdd(&sse[pair], err);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sse(const uint8_t* a, long long a_stride, int a_pitch, const uint8_t* b,
+                                              long long b_stride, int b_pitch, int H, int W,
+                                              unsigned long long* sse)
+{
+    const int pair = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    unsigned err = 0;
+    if (x < W && y < H) {
+        const int df = (int)a[(long long)pair * a_stride + (long long)y * a_pitch + x] -
+                       (int)b[(long long)pair * b_stride + (long long)y * b_pitch + x];
+        err = (unsigned)(df * df);
+    }
+    for (int m = 32; m > 0; m >>= 1) err += (unsigned)__shfl_xor((int)err, m, 64);
+    if ((threadIdx.x & 63) == 0 && err) atomicAdd(&sse[pair], (unsigned long long)err);
+}
+
+}  // namespace
+
+int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
+{
+    GME_REQUIRE(dst.H == (src.H + 1) / 2 && dst.W == (src.W + 1) / 2 && dst.count == src.count, GME_ERR_ARG,
+                "pyrdown: destination shape mismatch");
+    const dim3 grid((dst.W + 63) / 64, (dst.H + 3) / 4, src.count);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
+                       src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0)
+{
+    if (pairs == 0) return GME_OK;
+    hipLaunchKernelGGL(k_first_params, dim3(pairs), dim3(256), 0, ctx->stream, dense, n_blocks, params0);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out)
+{
+    if (pairs == 0 || h * w == 0) return GME_OK;
+    hipLaunchKernelGGL(k_affine_field, dim3((h * w + 255) / 256, pairs), dim3(256), 0, ctx->stream, params, h, w, out);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params, int drop,
+                     int level_H, int level_W, int16_t* model, uint8_t* mask, int32_t* diff, int32_t* thr,
+                     double* sums)
+{
+    if (pairs == 0) return GME_OK;
+    const double wgt = 1.0 / ((double)level_H * (double)level_W);      // motion.py:250
+    hipLaunchKernelGGL(k_fit_level, dim3(pairs), dim3(256), 0, ctx->stream, gt, h, w, params, drop, wgt, model, mask,
+                       diff, thr, sums);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride, int pairs, int H, int W, int pitch,
+                      const int32_t* mf32, const double* params, int h, int w, uint8_t* out, int64_t out_stride,
+                      int out_pitch, const uint8_t* cur, int64_t cur_stride, unsigned long long* sse)
+{
+    if (pairs == 0) return GME_OK;
+    if (sse) GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, pairs);
+    hipLaunchKernelGGL(k_compensate, grid, dim3(256), 0, ctx->stream, frames, (long long)frame_stride, H, W, pitch,
+                       mf32, params, h, w, out, (long long)out_stride, out_pitch, cur, (long long)cur_stride, sse);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_sse(gme_ctx* ctx, const uint8_t* a, int64_t a_stride, int a_pitch, const uint8_t* b, int64_t b_stride,
+               int b_pitch, int pairs, int H, int W, unsigned long long* sse)
+{
+    if (pairs == 0) return GME_OK;
+    GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, pairs);
+    hipLaunchKernelGGL(k_sse, grid, dim3(256), 0, ctx->stream, a, (long long)a_stride, a_pitch, b, (long long)b_stride,
+                       b_pitch, H, W, sse);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}

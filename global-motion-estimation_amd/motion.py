@@ -1,0 +1,126 @@
+"""Global motion estimation on MI355X -- drop-in for the reference's ``motion`` module.
+
+Same call surface as ``global_motion_estimation/motion.py``; pyramids, block matching,
+model fields, outlier masks, normal-equation sums, compensation run on the GPU
+(``csrc/*.hip`` through ``_gme_native``).  The only arithmetic left on the host is what
+the reference itself hands to NumPy/LAPACK per level: two 3x3 ``np.linalg.inv`` + matmul
+(motion.py:262-264,280-282) -- kept here so the parameters round exactly like the
+NumPy installed next to this module.
+
+``BBME_BLOCK_SIZE`` and ``MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE`` are read at call
+time, so the authors' habit of patching them (12/24/32 for their figures) keeps working.
+"""
+import numpy as np
+
+import _gme_native as _native
+from bbme import get_motion_field
+
+BBME_BLOCK_SIZE = 16                               # motion.py:9
+MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE = .3      # motion.py:10
+
+
+def dense_motion_estimation(previous, current):
+    """motion.py:13-30: diamond search on 2x2 blocks (MSE by default)."""
+    return get_motion_field(previous, current, block_size=2, searching_procedure=3)
+
+
+def _solve(sums):
+    """motion.py:262-264,280-286 for one pair: [a0,a1,a2,b0,b1,b2] from F | Sx | Sy."""
+    F = sums[:9].reshape(3, 3)
+    finv = np.array(np.linalg.inv(F))              # LinAlgError on a singular system, as upstream
+    ax = np.matmul(finv, sums[9:12].reshape(3, 1)).reshape((3,))
+    finv = np.array(np.linalg.inv(F))
+    ay = np.matmul(finv, sums[12:15].reshape(3, 1)).reshape((3,))
+    return np.concatenate([ax, ay])
+
+
+def _fit_pair(previous, current, old_parameters, fraction):
+    ctx = _native.default_context()
+    seq = _native.Sequence.from_frames(ctx, [previous, current])
+    try:
+        seq.bbme(1, int(BBME_BLOCK_SIZE), 2, 3, 1)                     # motion.py:224-229 (diamond, MSE)
+        p = np.asarray(old_parameters).astype(np.float64).reshape(1, 6)
+        return _solve(seq.gme_fit(-1, p, fraction)[0])
+    finally:
+        seq.close()
+
+
+def best_affine_parameters(previous, current):
+    """motion.py:33-88: the unmasked least-squares fit (no live caller upstream)."""
+    return _fit_pair(previous, current, np.zeros(6), -1.0)
+
+
+def best_affine_parameters_robust(previous, current, old_parameters):
+    """motion.py:210-286: BBME field, model field from `old_parameters`, top ~30 % of L1
+    deviations masked, weighted normal equations over the inliers, 3x3 solve."""
+    return _fit_pair(previous, current, old_parameters, float(MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE))
+
+
+def affine_model(x, y, parameters):
+    """motion.py:91-105 (host helper; the device evaluates the same expression per block)."""
+    A = np.asarray([[1, x, y, 0, 0, 0], [0, 0, 0, 1, x, y]], dtype=np.int32)
+    return np.matmul(A, np.transpose(parameters))
+
+
+def get_motion_field_affine(shape, parameters):
+    """motion.py:139-157: int16[shape[0], shape[1], 2] of round-half-even displacements."""
+    return _native.default_context().affine_field(parameters, int(shape[0]), int(shape[1]))
+
+
+def compute_first_parameters(dense_motion_field):
+    """motion.py:176-188."""
+    a0 = np.mean(dense_motion_field[:, :, 0])
+    b0 = np.mean(dense_motion_field[:, :, 1])
+    return np.array([a0, 0.0, 0.0, b0, 0.0, 0.0], dtype=np.float32)
+
+
+def first_parameter_estimation(previous, current):
+    """motion.py:160-173."""
+    return compute_first_parameters(dense_motion_estimation(previous, current))
+
+
+def parameter_projection(parameters):
+    """motion.py:191-207 -- in place."""
+    parameters[0] = parameters[0] * 2
+    parameters[3] = parameters[3] * 2
+    return parameters
+
+
+def estimate_sequence(seq, frame_distance=1, procedure=3, search_window=2):
+    """motion.global_motion_estimation for every pair of a device-resident sequence.
+
+    Returns float64[P, 6].  Three device phases (begin, fit level 1, fit level 2) with the
+    per-pair 3x3 solves on the host in between, exactly the order of motion.py:123-136.
+    """
+    frac = float(MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
+    params = seq.gme_begin(frame_distance, int(BBME_BLOCK_SIZE), procedure, search_window)   # float32[P,6]
+    for level in (1, 2):
+        for p in params:
+            parameter_projection(p)
+        sums = seq.gme_fit(level, params.astype(np.float64), frac)
+        params = np.stack([_solve(s) for s in sums]) if len(sums) else np.zeros((0, 6))
+    return params
+
+
+def global_motion_estimation(previous, current):
+    """motion.py:109-136 -> float64[6] = [a0, a1, a2, b0, b1, b2] at full resolution."""
+    ctx = _native.default_context()
+    seq = _native.Sequence.from_frames(ctx, [previous, current])
+    try:
+        return estimate_sequence(seq, 1)[0]
+    finally:
+        seq.close()
+
+
+def compensate_frame(frame, motion_field):
+    """motion.py:289-321: block-wise gather ``out[a, b] = frame[a - d[1], b - d[0]]`` where the
+    source lies inside the frame, else the pixel is kept."""
+    return _native.default_context().compensate(frame, motion_field)
+
+
+def motion_compensation(previous, current):
+    """motion.py:324-341."""
+    parameters = global_motion_estimation(previous, current)
+    shape = (previous.shape[0] // BBME_BLOCK_SIZE, previous.shape[1] // BBME_BLOCK_SIZE)
+    motion_field = get_motion_field_affine(shape, parameters)
+    return compensate_frame(previous, motion_field)

@@ -1,0 +1,142 @@
+/*
+ * gme_hip.h -- C ABI of libgme_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame-pair hot path of Samaretas/global-motion-estimation.
+ *
+ * The reference is pure Python and has no FFI; its boundary is the module surface
+ * of global_motion_estimation/{bbme,motion,utils}.py.  Each entry point below names
+ * the reference function(s) it replaces (paths relative to
+ * /root/reference/global_motion_estimation/).  The Python mirror of that surface
+ * (global-motion-estimation_amd/{bbme,motion,utils}.py) binds these symbols with
+ * ctypes; INTEGRATION.md shows the stub a maintainer would add upstream.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (GME_OK) or a negative GME_ERR_*;
+ *     gme_last_error() gives the text for the calling thread's last failure.
+ *   - host images are uint8, row-major, `stride` bytes between rows; motion fields
+ *     are int32[h][w][2] with [..][0] = column (x) and [..][1] = row (y)
+ *     displacement, position in `cur` minus position in `prev` (bbme.py:176-177).
+ *   - the caller allocates every output; the library owns device memory inside the
+ *     opaque gme_ctx / gme_seq objects; one HIP stream per context; a context is not
+ *     thread-safe (the reference is single-threaded).
+ *   - integer results (motion vectors, masks, model fields, compensated frames,
+ *     squared-error sums) are bit-exact with the reference; the normal-equation
+ *     sums are bit-exact float64; the 3x3 solve stays on the host (NumPy) because
+ *     LAPACK builds differ in the last bits.
+ */
+#ifndef GME_HIP_H
+#define GME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GME_API __attribute__((visibility("default")))
+#else
+#define GME_API
+#endif
+
+typedef struct gme_ctx gme_ctx;   /* one device + one stream + scratch */
+typedef struct gme_seq gme_seq;   /* a frame sequence resident in HBM + per-pair results */
+
+enum {
+    GME_OK = 0,
+    GME_ERR_ARG = -1,        /* bad pointer / size / index (reference: IndexError, bbme.py:27,60) */
+    GME_ERR_INEXACT = -2,    /* block distance leaves float32's exact-integer range (bbme.py:61-64) */
+    GME_ERR_GEOMETRY = -3,   /* frame smaller than the search needs (reference: AssertionError, bbme.py:59) */
+    GME_ERR_HIP = -4,        /* HIP runtime failure */
+    GME_ERR_STATE = -5,      /* call order violated (e.g. fit before begin) */
+    GME_ERR_NOMEM = -6
+};
+
+/* bbme.py:609-614 searching_procedures, bbme.py:608 pnorm_distances */
+enum { GME_SEARCH_EXHAUSTIVE = 0, GME_SEARCH_THREESTEP = 1, GME_SEARCH_TWODLOG = 2, GME_SEARCH_DIAMOND = 3 };
+enum { GME_NORM_MAE = 0, GME_NORM_MSE = 1 };
+
+GME_API const char *gme_last_error(void);
+GME_API int gme_device_count(void);
+GME_API gme_ctx *gme_create(int device_id);
+GME_API void gme_destroy(gme_ctx *ctx);
+GME_API int gme_sync(gme_ctx *ctx);
+GME_API int gme_device_info(gme_ctx *ctx, char *name, int name_len, int *cu_count, int *clock_khz);
+/* opaque handle of the context's HIP stream (hipStream_t), for callers that
+ * want to order their own work or events after the library's */
+GME_API void *gme_stream(gme_ctx *ctx);
+
+/* HIP-event stopwatch on the context's stream (bench.py: kernel time of the timed region) */
+GME_API int gme_timer_start(gme_ctx *ctx);
+GME_API int gme_timer_stop(gme_ctx *ctx, float *elapsed_ms);   /* synchronises */
+
+/* ---------------------------------------------------------------------------
+ * Single-pair calls on host buffers (H2D, kernel, D2H inside the call).
+ * ------------------------------------------------------------------------- */
+
+/* bbme.get_motion_field (bbme.py:12-38) with the four searches (bbme.py:105-534).
+ * mf_out: int32[H/bs][W/bs][2]. */
+GME_API int gme_bbme_u8(gme_ctx *ctx, const uint8_t *prev, const uint8_t *cur, int H, int W, int stride,
+                int block_size, int search_window, int procedure, int pnorm, int32_t *mf_out);
+
+/* cv2.pyrDown as called by utils.get_pyramids (utils.py:34-51); dst is ((H+1)/2) x ((W+1)/2), tight. */
+GME_API int gme_pyrdown_u8(gme_ctx *ctx, const uint8_t *src, int H, int W, int stride, uint8_t *dst);
+
+/* motion.get_motion_field_affine (motion.py:139-157): int16[h][w][2], round-half-even. */
+GME_API int gme_affine_field(gme_ctx *ctx, const double params[6], int h, int w, int16_t *mf_out);
+
+/* motion.compensate_frame (motion.py:289-321); mf is int32[h][w][2]; out is H x W, tight. */
+GME_API int gme_compensate_u8(gme_ctx *ctx, const uint8_t *frame, int H, int W, int stride,
+                      const int32_t *mf, int h, int w, uint8_t *out);
+
+/* integer core of utils.PSNR (utils.py:100-116): sum over pixels of (a-b)^2. */
+GME_API int gme_sse_u8(gme_ctx *ctx, const uint8_t *a, const uint8_t *b, int H, int W, int stride_a,
+               int stride_b, int64_t *sse_out);
+
+/* ---------------------------------------------------------------------------
+ * Sequence API: N frames resident in HBM; pair p = (frame p, frame p + fd) as in
+ * results.py:41-48.  This is the batch form of the hot path and what bench.py times.
+ * ------------------------------------------------------------------------- */
+GME_API gme_seq *gme_seq_create(gme_ctx *ctx, int n_frames, int H, int W);
+GME_API void gme_seq_destroy(gme_seq *seq);
+GME_API int gme_seq_upload(gme_seq *seq, int first, int count, const uint8_t *frames, int row_stride,
+                   int64_t frame_stride);
+/* deterministic synthetic frames t0 .. t0+N-1 generated on the device */
+GME_API int gme_seq_synth(gme_seq *seq, uint64_t seed, int t0);
+/* level 2 = full resolution, 1 and 0 = pyramid levels (valid after gme_seq_gme_begin) */
+GME_API int gme_seq_read_frame(gme_seq *seq, int level, int index, uint8_t *out);
+
+/* bbme.get_motion_field over every pair of the sequence; results stay on the device */
+GME_API int gme_seq_bbme(gme_seq *seq, int frame_distance, int block_size, int search_window,
+                 int procedure, int pnorm);
+GME_API int gme_seq_read_mv(gme_seq *seq, int first_pair, int count, int32_t *mf_out);
+
+/* motion.global_motion_estimation (motion.py:109-136), staged so that the host does
+ * the 3x3 solves (motion.py:262-264,280-282) between levels:
+ *   begin : pyramids (utils.py:34-51) of all frames, diamond BBME at the three levels
+ *           (motion.py:27-29,224-229), first parameters (motion.py:176-188) -> float32[P][6]
+ *   fit   : for level 1 or 2 and parameters already projected by the caller
+ *           (motion.py:191-207): model field, L1 difference, threshold, outlier mask,
+ *           sequential float64 normal-equation sums (motion.py:232-279)
+ *           -> sums_out[P][15] = F (9, row-major) | Sx (3) | Sy (3)
+ * `procedure` / `search_window` select the BBME used at levels 1 and 2 (the reference
+ * hard-codes diamond, GME_SEARCH_DIAMOND; exhaustive serves BASELINE config 4). */
+GME_API int gme_seq_gme_begin(gme_seq *seq, int frame_distance, int bbme_block_size, int procedure,
+                      int search_window, float *params0_out);
+GME_API int gme_seq_gme_fit(gme_seq *seq, int level, const double *params_in, double outlier_fraction,
+                    double *sums_out);
+/* stage read-back for parity tests; any pointer may be NULL.
+ * level 0: gt = dense field (bs 2); levels 1, 2: gt, model (int16), mask, threshold */
+GME_API int gme_seq_gme_read_stage(gme_seq *seq, int level, int pair, int32_t *gt, int16_t *model,
+                           uint8_t *mask, int64_t *threshold);
+
+/* motion.get_motion_field_affine((H/bs, W/bs), params) + motion.compensate_frame(prev, field)
+ * + sum of squared error against `cur` for every pair (results.py:52-59,109).
+ * Compensated frames stay on the device; sse_out[P] may be NULL. */
+GME_API int gme_seq_compensate(gme_seq *seq, int frame_distance, int block_size, const double *params,
+                       int64_t *sse_out);
+GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GME_HIP_H */

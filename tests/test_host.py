@@ -1,0 +1,141 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/gme_hip.h declares,
+host logic (sharding, gather over gloo with 2 ranks, table indices, 3x3 solve), and the
+product path's refusal to run without its native library or a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import _gme_native
+    header = open(os.path.join(REPO, "include", "gme_hip.h")).read()
+    declared = set(re.findall(r"GME_API [^;(]*?\b(gme_\w+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = _gme_native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the ctypes signature table covers exactly the header
+    assert declared == set(_gme_native.exported_symbols())
+
+
+def test_no_device_means_loud_failure():
+    """No GPU in the build container: the product path must raise, never fall back."""
+    import _gme_native
+    lib = _gme_native.load_library()
+    if lib.gme_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    import bbme
+    f = np.zeros((32, 32), np.uint8)
+    with pytest.raises(_gme_native.GmeError):
+        bbme.get_motion_field(f, f)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    import _gme_native
+    monkeypatch.setattr(_gme_native, "_lib", None)
+    monkeypatch.setattr(_gme_native, "LIB_PATH", "/nonexistent/libgme_hip.so")
+    with pytest.raises(_gme_native.GmeError, match="no CPU fallback"):
+        _gme_native.load_library()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "global-motion-estimation_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "gme_oracle" not in text.replace("oracle/gme_oracle.py affine_field", ""), f
+                assert "libgme_oracle" not in text, f
+
+
+def test_table_indices_follow_python_lists():
+    import bbme
+    assert bbme._table_index(-1, 4, "x") == 3 and bbme._table_index(2, 4, "x") == 2
+    with pytest.raises(IndexError):
+        bbme._table_index(4, 4, "x")
+    with pytest.raises(IndexError):
+        bbme._table_index(-5, 4, "x")
+    a = np.arange(16, dtype=np.uint8).reshape(4, 4)
+    b = a[::-1].copy()
+    assert bbme.compute_dfd(a, b, 0) == np.float32(np.abs(a.astype(int) - b).sum())
+    assert bbme.compute_dfd(a, b, 1) == np.float32(((a.astype(int) - b) ** 2).sum())
+    with pytest.raises(AssertionError):
+        bbme.compute_dfd(a, b[:2])
+    assert len(bbme.searching_procedures) == 4 and len(bbme.pnorm_distances) == 2
+
+
+def test_solve_matches_oracle_and_raises_on_singular(golden):
+    import motion
+    from oracle import gme_oracle
+    g = golden("g4_gme")
+    sums = np.concatenate([g["race_l2_F"].reshape(9), g["race_l2_Sx"], g["race_l2_Sy"]])
+    got = motion._solve(sums)
+    assert np.array_equal(got, gme_oracle.solve_parameters(g["race_l2_F"], g["race_l2_Sx"], g["race_l2_Sy"]))
+    np.testing.assert_allclose(got, g["race_params"], rtol=1e-10, atol=1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        motion._solve(np.zeros(15))
+    p = np.array([1.5, 0, 0, -2.25, 0, 0], np.float32)
+    assert motion.parameter_projection(p) is p and p[0] == 3.0 and p[3] == -4.5
+    d = motion.affine_model(3, 4, np.array([1.0, .5, .25, -1, 0, 2]))
+    assert d.shape == (2,) and d[0] == 1 + 1.5 + 1 and d[1] == 7
+
+
+def test_shard_ranges_cover_pairs_once():
+    import sequence
+    for n in (0, 1, 5, 8, 1999):
+        for world in (1, 2, 3, 8):
+            spans = [sequence.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert sequence.shard_frames(1999, 1, 7, 8) == (1749, 251)
+    assert sequence.shard_frames(3, 2, 1, 8) == (0, 0)
+    with pytest.raises(ValueError):
+        sequence.shard_range(4, 2, 2)
+
+
+_GATHER = r'''
+import os, sys
+sys.path[:0] = [%(pkg)r]
+import numpy as np, torch.distributed as dist
+import sequence
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 7
+a, b = sequence.shard_range(n, rank, world)
+local = np.arange(n * 6, dtype=np.float64).reshape(n, 6)[a:b] * 1.5
+full = sequence.gather_parameters(local, n, rank, world)
+assert full.shape == (n, 6) and np.array_equal(full, np.arange(n * 6, dtype=np.float64).reshape(n, 6) * 1.5)
+empty = sequence.gather_parameters(np.zeros((1 if rank == 0 else 0, 6)), 1, rank, world)
+assert empty.shape == (1, 6)
+dist.barrier()
+dist.destroy_process_group()
+sys.stdout.write("rank" + str(rank) + " ok\n")
+'''
+
+
+def test_gather_over_gloo_world_2(tmp_path):
+    script = tmp_path / "gather.py"
+    script.write_text(_GATHER % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank0 ok" in out.stdout and "rank1 ok" in out.stdout
+
+
+def test_synth_generator_self_checks():
+    """SURVEY.md §8(d) constants."""
+    import synth
+    from helpers import sha
+    assert int(synth.hash64(1234, 0)) == 0xdf34b78a642501be and int(synth.hash64(1234, 1)) == 0x9bbdb63ded02052d
+    assert list(synth.canvas(1234)[0, :8]) == [140, 141, 145, 142, 143, 135, 134, 141]
+    assert sha(synth.frame(1234, 0, 480, 720)) == "9736c2ac7184b594c41cb75edac231feac5775691bca78fc0af2cb8674ae7308"
+    assert sha(synth.frame(1234, 1, 480, 720)) == "9652a5b6f736753131bdcc1961978ceb4238d311bb56ddba6e66d15ddffa7217"
