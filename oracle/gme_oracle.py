@@ -55,9 +55,13 @@ def _inside(top, left, bs, height, width):
 # --------------------------------------------------------------------------
 # exhaustive search -- bbme.py:105-179
 # --------------------------------------------------------------------------
-def search_exhaustive(previous, current, mf, height, width, pnorm, bs, sw):
+def search_exhaustive(previous, current, mf, height, width, pnorm, bs, sw, block_rows=None):
+    """`block_rows=(lo, hi)` restricts the block loop to those block rows (bench.py's
+    bounded CPU sample); everything else is the full-frame search."""
     span = range(-sw, sw + bs)            # asymmetric window, bbme.py:146-149
     for r0, c0 in _block_origins(height, width, bs):
+        if block_rows is not None and not block_rows[0] <= r0 // bs < block_rows[1]:
+            continue
         anchor = previous[r0:r0 + bs, c0:c0 + bs]
         best = _INF
         best_col = best_row = 0

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs of one gpurun_out/<tag>/ directory into a small text file
+(per kernel: mean counter value per dispatch).  Usage: tools/pmc_summary.py gpurun_out/<tag> [kernel-substring]"""
+import collections
+import csv
+import re
+import glob
+import sys
+
+def kname(full):
+    m = re.search(r"(k_\w+(<[^>]*>)?)", full)
+    return m.group(1) if m else full[:50]
+
+
+root = sys.argv[1]
+needle = sys.argv[2] if len(sys.argv) > 2 else ""
+print("# source: %s (rocprofv3 --pmc <counters> --kernel-trace, separate passes)" % root)
+for path in sorted(glob.glob(root + "/pmc_*/*/*_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        if needle in r["Kernel_Name"]:
+            agg[(kname(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            meta[kname(r["Kernel_Name"])] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    for (k, c), v in sorted(agg.items()):
+        print("%-50s %-24s dispatches=%-3d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+    for k, m in meta.items():
+        print("#   %s grid=%s wg=%s lds=%s vgpr=%s sgpr=%s" % ((k,) + m))
