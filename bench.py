@@ -34,6 +34,12 @@ CONFIGS = {
     "exh720mse": (480, 720, 16, 16, 0, 1, 1234, "720x480 synthetic luma, bs=16 sw=16 exhaustive MSE"),
     "exh1080": (1080, 1920, 16, 32, 0, 0, 4321, "1920x1080 synthetic luma, bs=16 sw=32 exhaustive MAE"),
     "dia720": (480, 720, 16, 16, 3, 0, 1234, "720x480 synthetic luma, bs=16 diamond MAE"),
+    "dia720mse": (480, 720, 16, 16, 3, 1, 1234, "720x480 synthetic luma, bs=16 diamond MSE"),
+    # full GME: procedure/pnorm fields unused (the reference hard-codes diamond + MSE, motion.py:27,224)
+    "gme720": (480, 720, 16, 2, -1, 1, 1234, "720x480 full multiscale affine GME (3-level pyramid + diamond BBME + "
+               "outlier mask + compensate + PSNR), BASELINE configs[2]"),
+    "gme1080": (1080, 1920, 16, 2, -1, 1, 2000, "1920x1080 synthetic sequence, diamond-search GME + compensate, "
+                "BASELINE configs[4] per-GPU shard"),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # measured on MI355X (tools/microbench/valu_rates2.hip, profiles/r01_valu_rates.txt):
@@ -42,7 +48,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 QSAD_PEAK_OPS = 1024 * 1024 / 6.9e-9
 
 
-def algorithmic_bytes(H, W, bs):
+def algorithmic_bytes(H, W, bs, gme=False):
+    if gme:
+        return 3 * H * W + 48                               # 2 frames in, 1 compensated frame out, params
     return 2 * H * W + 8 * (H // bs) * (W // bs)
 
 
@@ -110,8 +118,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        local = local % max(ndev, 1)               # rehearsals may put several ranks on one card
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("GME_BENCH_BACKEND", "nccl")      # nccl = RCCL; gloo only for rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -126,8 +140,20 @@ def main():
     seq.synth(seed, rank * B)                      # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
     ctx.sync()
 
-    def step():
-        seq.bbme(1, bs, sw, proc, pnorm)           # asynchronous launch on the context's stream
+    gme = proc < 0
+    if gme:
+        import motion
+        last = {}
+
+        def step():
+            # motion.global_motion_estimation + results.py:52-59,109 for every resident pair;
+            # frames change between videos, so the pyramids are rebuilt inside the step
+            seq.invalidate_pyramids()
+            params = motion.estimate_sequence(seq, 1)
+            last["params"], last["sse"] = params, seq.compensate(1, int(motion.BBME_BLOCK_SIZE), params)
+    else:
+        def step():
+            seq.bbme(1, bs, sw, proc, pnorm)       # asynchronous launch on the context's stream
 
     for _ in range(args.warmup):
         step()
@@ -142,24 +168,32 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # parity gate printed with the number: rank 0's first pair is the golden pair (seed 1234, t=0,1)
     parity = None
-    mv = seq.read_mv(0, 1)[0]
+    mv = None if gme else seq.read_mv(0, 1)[0]
     gpath = os.path.join(REPO, "tests", "golden", "g2_synth720.npz")
-    if rank == 0 and args.config in ("exh720", "exh720mse", "dia720") and os.path.exists(gpath):
+    if rank == 0 and args.config in ("exh720", "exh720mse", "dia720", "dia720mse") and os.path.exists(gpath):
         parity = bool(np.array_equal(mv, np.load(gpath)["mf_sp%d_pn%d" % (proc, pnorm)]))
+    if rank == 0 and args.config == "gme720":
+        g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_gme.npz"))
+        import hashlib
+        comp_sha = hashlib.sha256(seq.read_compensated(0).tobytes()).hexdigest()
+        parity = bool(np.allclose(last["params"][0], g4["synth720_params"], rtol=1e-10, atol=1e-12)
+                      and comp_sha == str(g4["synth720_comp_sha"]))
 
     if rank == 0:
         total_pairs = world * B * args.steps
         value = total_pairs / elapsed
-        abytes = algorithmic_bytes(H, W, bs) * B
+        abytes = algorithmic_bytes(H, W, bs, gme) * B
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive, 1->8 GPU",
+            "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive, 1->8 GPU"
+                      if args.config == "exh720" else "frame-pairs/s, " + args.config,
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -167,7 +201,8 @@ def main():
                        "sharding": "frame pairs across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_exh_qsad16<3>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else "see DESIGN.md",
+                         "kernel": "k_exh_qsad16<3>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
+                                   ("whole step (all kernels + host solves)" if gme else "see DESIGN.md"),
                          "kernel_ms_per_launch": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "parity_first_pair_vs_reference_golden": parity,

@@ -8,6 +8,7 @@ Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "gme_seq_upload": (_i, [_vp, _i, _i, _c_u8p, _i, ctypes.c_int64]),
     "gme_seq_synth": (_i, [_vp, ctypes.c_uint64, _i]),
     "gme_seq_read_frame": (_i, [_vp, _i, _i, _c_u8p]),
+    "gme_seq_invalidate": (_i, [_vp]),
     "gme_seq_bbme": (_i, [_vp, _i, _i, _i, _i, _i]),
     "gme_seq_read_mv": (_i, [_vp, _i, _i, _c_i32p]),
     "gme_seq_gme_begin": (_i, [_vp, _i, _i, _i, _i, _c_f32p]),
@@ -137,12 +139,15 @@ class Context:
             if n > 0:
                 device %= n
         self.device = device
+        self._sequences = weakref.WeakSet()
         self.handle = self.lib.gme_create(device)
         if not self.handle:
             raise GmeError("cannot open HIP device %d: %s" % (device, self.lib.gme_last_error().decode()))
 
     def close(self):
         if getattr(self, "handle", None):
+            for seq in list(self._sequences):      # sequences hold device memory of this context
+                seq.close()
             self.lib.gme_destroy(self.handle)
             self.handle = None
 
@@ -225,6 +230,7 @@ class Sequence:
         self.handle = self.lib.gme_seq_create(ctx.handle, self.N, self.H, self.W)
         if not self.handle:
             raise GmeError("gme_seq_create failed: %s" % self.lib.gme_last_error().decode())
+        ctx._sequences.add(self)
         self._gme = None
 
     @classmethod
@@ -246,7 +252,8 @@ class Sequence:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.gme_seq_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):  # the context may already be gone at interpreter exit
+                self.lib.gme_seq_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -264,6 +271,11 @@ class Sequence:
 
     def synth(self, seed, t0=0):
         _check(self.lib.gme_seq_synth(self.handle, seed, t0), self.lib)
+
+    def invalidate_pyramids(self):
+        """Force the next gme_begin to rebuild pyramid levels 1 and 0 (done automatically after
+        upload/synth; bench.py uses it so that every timed step pays for its pyramids)."""
+        _check(self.lib.gme_seq_invalidate(self.handle), self.lib)
 
     def level_shape(self, level):
         h, w = self.H, self.W

@@ -53,17 +53,25 @@ __global__ void k_exh_qsad16(FastDev d)
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
 
     // ---- stage the search window (coalesced dword loads; out-of-frame -> 0) ----
+    // thread -> one dword column and every `rstep`-th row: no div/mod inside the loop
     {
         const int gx0 = bcol0 * 16 - d.sw;             // multiple of 4 (sw % 4 == 0)
         const int gy0 = r0 - d.sw;
-        const int n = d.win_rows * d.pitch_dw;
-        for (int e = threadIdx.x; e < n; e += blockDim.x) {
-            const int row = e / d.pitch_dw, dw = e - row * d.pitch_dw;
-            const int gy = gy0 + row, gx = gx0 + 4 * dw;
-            uint32_t v = 0;
-            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.pitch)
-                v = *(const uint32_t*)(cur + (long long)gy * d.pitch + gx);
-            win[e] = v;
+        const int rstep = blockDim.x / d.pitch_dw;
+        const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
+        const int gx = gx0 + 4 * dw;
+        const bool colok = gx >= 0 && gx < d.pitch;
+        if (row0 < rstep) {
+            const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
+            const long long sstep = (long long)rstep * d.pitch;
+            uint32_t* dst = win + row0 * d.pitch_dw + dw;
+            const int dstep = rstep * d.pitch_dw;
+            for (int row = row0; row < d.win_rows; row += rstep, src += sstep, dst += dstep) {
+                const int gy = gy0 + row;
+                uint32_t v = 0;
+                if (colok && gy >= 0 && gy < d.H) v = *(const uint32_t*)src;
+                *dst = v;
+            }
         }
     }
     __syncthreads();
@@ -111,22 +119,48 @@ __global__ void k_exh_qsad16(FastDev d)
     }
 
     // ---- pick the first minimum in the reference's scan order ----
+    // Lane-local keys: sad << 16 | local, local = (4k+e)*R + i grows with the scan order
+    // (column index outer, row index inner) inside a lane; one op builds a key from a packed
+    // accumulator half: (dword << 16) | local for the low u16, (dword & 0xFFFF0000) | local
+    // for the high one.
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
     const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
+    const bool interior = __builtin_amdgcn_readfirstlane(lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1);
+    uint32_t lbest = 0xFFFFFFFFu;
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t dwv = (uint32_t)(acc[i][k] >> (32 * (e >> 1)));
+                    const uint32_t local = (uint32_t)((4 * k + e) * R + i);
+                    const uint32_t key = (e & 1) ? ((dwv & 0xFFFF0000u) | local) : ((dwv << 16) | local);
+                    lbest = min(lbest, key);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ri = prow * R + i;
+            const bool rok = ri >= lo_r && ri <= hi_r;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = q * 4 * R + 4 * k + e;
+                    const uint32_t dwv = (uint32_t)(acc[i][k] >> (32 * (e >> 1)));
+                    const uint32_t local = (uint32_t)((4 * k + e) * R + i);
+                    const uint32_t key = (e & 1) ? ((dwv & 0xFFFF0000u) | local) : ((dwv << 16) | local);
+                    if (rok && ci >= lo_c && ci <= hi_c) lbest = min(lbest, key);
+                }
+        }
+    }
     uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int ri = prow * R + i;
-        const bool rok = ri >= lo_r && ri <= hi_r;
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ci = q * 4 * R + 4 * k + e;
-                const uint32_t sad = (uint32_t)(acc[i][k] >> (16 * e)) & 0xFFFFu;
-                const uint32_t key = (sad << 13) | (uint32_t)(ci * NC + ri);
-                if (rok && ci >= lo_c && ci <= hi_c) best = min(best, key);
-            }
+    if (lbest != 0xFFFFFFFFu) {
+        const int local = lbest & 0xFFFF;
+        const int ce = local / R, i = local - ce * R;
+        best = ((lbest >> 16) << 13) | (uint32_t)((q * 4 * R + ce) * NC + prow * R + i);
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m, 64));

@@ -12,6 +12,8 @@
 //                     packed (cost, scan index) keys min-reduced across the wave.
 //   k_exh_generic     exhaustive, any geometry / norm (one 256-thread group per block)
 //   k_walk<G>         three-step / 2-D log / diamond walks, G lanes per block
+#include <stdlib.h>
+
 #include "gme_internal.h"
 
 namespace {
@@ -261,6 +263,7 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
 }
 
 int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
+int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
 {
@@ -279,6 +282,10 @@ int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
     bool handled = false;
     rc = launch_bbme_fast(ctx, job, &handled);
     if (rc != GME_OK || handled) return rc;
+    if (!getenv("GME_FORCE_GENERIC")) {
+        rc = launch_bbme_walk_fast(ctx, job, &handled);
+        if (rc != GME_OK || handled) return rc;
+    }
 
     d.status = ctx->status;
 

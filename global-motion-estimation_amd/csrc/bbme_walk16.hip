@@ -1,0 +1,312 @@
+// Walk searches (diamond, three-step, 2-D log) specialised for the two geometries the
+// global-motion pipeline runs all the time (motion.py:27-29,224-229):
+//
+//   k_walk16<PNORM>   bs = 16: one wavefront per macroblock.  The wave is cut into 8 groups
+//                     of 8 lanes; a group evaluates one candidate per round, each lane owning
+//                     two 16-byte rows of the block (two unaligned 16-byte loads of `cur`,
+//                     8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8 anchor dwords kept in VGPRs),
+//                     followed by a 3-step xor reduction inside the group.  Up to 8 candidates
+//                     cost one round; the centre of a pattern is usually the previous winner,
+//                     whose cost is carried instead of recomputed.
+//   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
+//                     coarsest pyramid level, 5400 blocks per 720x480 pair).
+//
+// Candidate order, clamping/validity rules and tie-breaking are those of
+// bbme.py:182-534 (see bbme_kernels.hip for the generic form and the quirk list).
+#include "gme_internal.h"
+
+namespace {
+
+struct WalkDev {
+    const uint8_t* prev;
+    const uint8_t* cur;
+    long long plane_stride;
+    int pairs, H, W, pitch, sw, procedure;
+    int nbr, nbc;
+    int32_t* mf;
+    int* status;
+};
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint16_t u16_u __attribute__((aligned(1)));
+
+constexpr unsigned INF32 = 0xFFFFFFFFu;
+
+__device__ __forceinline__ int clamp_ref(int v, int hi)   // min(max(v, 0), hi), bbme.py:503-504
+{
+    const int t = v > 0 ? v : 0;
+    return t < hi ? t : hi;
+}
+
+// cost of up to 8 candidates (one per 8-lane group); positions are wave-uniform arrays.
+// Returns the group's candidate cost in every lane of the group (INF32 if !valid).
+template <int PNORM>
+__device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned aa, const uint8_t* cur, int pitch,
+                                               int rr, int cc, bool valid, int lrow)
+{
+    unsigned part = 0;
+    if (valid) {
+        // dword-aligned loads + v_alignbyte: byte-misaligned 16-byte loads are legal on gfx950
+        // but crawl through the texture addresser (measured 4x slower end to end)
+        const uint8_t* p = cur + (long long)(rr + lrow) * pitch + (cc & ~3);
+        const uint32_t sh = (uint32_t)cc & 3u;
+        const u32x4_a4 l0 = *(const u32x4_a4*)p, l1 = *(const u32x4_a4*)(p + pitch);
+        const uint32_t t0 = *(const uint32_t*)(p + 16), t1 = *(const uint32_t*)(p + pitch + 16);
+        const uint32_t b[8] = { __builtin_amdgcn_alignbyte(l0.y, l0.x, sh), __builtin_amdgcn_alignbyte(l0.z, l0.y, sh),
+                                __builtin_amdgcn_alignbyte(l0.w, l0.z, sh), __builtin_amdgcn_alignbyte(t0, l0.w, sh),
+                                __builtin_amdgcn_alignbyte(l1.y, l1.x, sh), __builtin_amdgcn_alignbyte(l1.z, l1.y, sh),
+                                __builtin_amdgcn_alignbyte(l1.w, l1.z, sh), __builtin_amdgcn_alignbyte(t1, l1.w, sh) };
+        if (PNORM == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part = __builtin_amdgcn_sad_u8(a[j], b[j], part);
+        } else {
+            unsigned bb = 0, ab = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
+                ab = __builtin_amdgcn_udot4(a[j], b[j], ab, false);
+            }
+            part = aa + bb - 2u * ab;          // sum over this lane's 32 pixels of (a-b)^2
+        }
+    }
+    part += __shfl_xor((int)part, 1, 64);
+    part += __shfl_xor((int)part, 2, 64);
+    part += __shfl_xor((int)part, 4, 64);
+    return valid ? part : INF32;
+}
+
+template <int PNORM>
+__global__ void __launch_bounds__(256) k_walk16(WalkDev d)
+{
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long gid = (long long)blockIdx.x * 4 + wave_in_wg;
+    const int nblk = d.nbr * d.nbc;
+    if (gid >= (long long)nblk * d.pairs) return;              // wave-uniform
+    const int pair = (int)(gid / nblk), blk = (int)(gid % nblk);
+    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, lrow = (lane & 7) * 2;           // group = candidate slot, lane = 2 block rows
+    const int H = d.H, W = d.W, pitch = d.pitch;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)(r0 + lrow) * pitch + c0;
+
+    uint32_t a[8];
+    {
+        const uint4 a0 = *(const uint4*)ap, a1 = *(const uint4*)(ap + pitch);     // 16-byte aligned
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+    }
+    unsigned aa = 0;
+    if (PNORM == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aa = __builtin_amdgcn_udot4(a[j], a[j], aa, false);
+    }
+
+    // evaluate n <= 8 candidates (cr[k], cc[k], ok[k]) -> cost[k], all wave-uniform
+#define EVAL8(n, CR, CC, OK, COST)                                                                   \
+    do {                                                                                             \
+        int rr_ = 0, cc_ = 0; bool ok_ = false;                                                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (grp == k_) { rr_ = CR[k_]; cc_ = CC[k_]; ok_ = OK[k_]; } \
+        const unsigned c_ = group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);               \
+        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
+    } while (0)
+
+    int out0 = 0, out1 = 0;
+    bool overrun = false;
+    const int cap = 2 * (H + W) + 64;
+
+    if (d.procedure == GME_SEARCH_DIAMOND) {
+        const int maxr = H - 16 - 1, maxc = W - 16 - 1;
+        const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };   // LDSP minus its centre
+        int pr = r0, pc = c0;
+        unsigned centre_cost;
+        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once
+            int cr[1] = { clamp_ref(pr, maxr) }, cc[1] = { clamp_ref(pc, maxc) };
+            bool ok[1] = { true };
+            unsigned cost[1];
+            EVAL8(1, cr, cc, ok, cost);
+            centre_cost = cost[0];
+        }
+        int it = 0;
+        for (;;) {
+            // candidate 0 of the pattern is the clamped centre itself
+            unsigned best = centre_cost;
+            int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
+            int cr[8], cc[8]; bool ok[8]; unsigned cost[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { cr[k] = clamp_ref(pr + ldr[k], maxr); cc[k] = clamp_ref(pc + ldc[k], maxc); ok[k] = true; }
+            EVAL8(8, cr, cc, ok, cost);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            const bool done = (br == pr && bc == pc);
+            pr = br; pc = bc; centre_cost = best;              // next centre is already clamped
+            if (done) break;
+            if (++it > cap) { overrun = true; break; }
+        }
+        // small pattern, offsets applied swapped (bbme.py:518-521): (0,0),(1,0),(0,1),(-1,0),(0,-1) -> row += o[1], col += o[0]
+        {
+            const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
+            unsigned best = centre_cost;
+            int br = pr, bc = pc;
+            int cr[4], cc[4]; bool ok[4]; unsigned cost[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cr[k] = clamp_ref(pr + sdr[k], maxr); cc[k] = clamp_ref(pc + sdc[k], maxc); ok[k] = true; }
+            EVAL8(4, cr, cc, ok, cost);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            out1 = br - r0; out0 = bc - c0;
+        }
+    } else if (d.procedure == GME_SEARCH_THREESTEP) {
+        const int n = 2 * d.sw + 16;
+        const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };
+        int drow = 0, dcol = 0, trow = 0, tcol = 0, org_r = r0, org_c = c0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int st = steps[s];
+            // scan order: column offset outer, row offset inner, each over (-st, 0, st)
+            int cr[9], cc[9], wr[9], wc[9]; bool ok[9]; unsigned cost[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                wc[k] = (k / 3 - 1) * st; wr[k] = (k % 3 - 1) * st;
+                cr[k] = org_r + wr[k]; cc[k] = org_c + wc[k];
+                ok[k] = cr[k] >= 0 && cc[k] >= 0 && cr[k] + 16 <= H && cc[k] + 16 <= W;
+            }
+            EVAL8(8, cr, cc, ok, cost);
+            {
+                int cr1[1] = { cr[8] }, cc1[1] = { cc[8] }; bool ok1[1] = { ok[8] }; unsigned c1[1];
+                EVAL8(1, cr1, cc1, ok1, c1);
+                cost[8] = c1[0];
+            }
+            unsigned best = INF32;
+            int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) if (ok[k] && cost[k] < best) { best = cost[k]; kr = wr[k]; kc = wc[k]; }
+            if (s == 0) { drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol; }
+            else { trow = kr; tcol = kc; drow += trow; dcol += tcol; org_r += drow; org_c += dcol; }
+        }
+        out0 = dcol; out1 = drow;
+    } else {   // 2-D log
+        int br = 0, bc = 0, pr = r0, pc = c0, step = d.sw, it = 0;
+        while (step > 1) {
+            int cr[9], cc[9]; bool ok[9]; unsigned cost[9];
+            const bool cross = step > 2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (cross) {
+                    cr[k] = pr + (k == 1 ? step : k == 2 ? -step : 0);
+                    cc[k] = pc + (k == 3 ? step : k == 4 ? -step : 0);
+                    ok[k] = k < 5;
+                } else {
+                    cr[k] = pr + (k / 3 - 1) * 2; cc[k] = pc + (k % 3 - 1) * 2; ok[k] = true;
+                }
+                ok[k] = ok[k] && cr[k] >= 0 && cc[k] >= 0 && cr[k] + 16 <= H && cc[k] + 16 <= W;
+            }
+            EVAL8(8, cr, cc, ok, cost);
+            {
+                int cr1[1] = { cr[8] }, cc1[1] = { cc[8] }; bool ok1[1] = { ok[8] }; unsigned c1[1];
+                EVAL8(1, cr1, cc1, ok1, c1);
+                cost[8] = c1[0];
+            }
+            unsigned best = INF32;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) if (ok[k] && cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            if ((br == pr && bc == pc) || step == 2) step /= 2;
+            pr = br; pc = bc;
+            if (++it > cap) { overrun = true; break; }
+        }
+        out1 = br - r0; out0 = bc - c0;
+    }
+#undef EVAL8
+    if (lane == 0) {
+        if (overrun) atomicExch(d.status, 1);
+        int32_t* o = d.mf + gid * 2;
+        o[0] = out0; o[1] = out1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dense 2x2 diamond search, one lane per block
+// ---------------------------------------------------------------------------
+template <int PNORM>
+__device__ __forceinline__ unsigned cost2x2(uint32_t a, unsigned aa, const uint8_t* cur, int pitch, int rr, int cc)
+{
+    const uint8_t* p = cur + (long long)rr * pitch + cc;
+    const uint32_t b = (uint32_t)(*(const u16_u*)p) | ((uint32_t)(*(const u16_u*)(p + pitch)) << 16);
+    if (PNORM == 0) return __builtin_amdgcn_sad_u8(a, b, 0u);
+    return aa + __builtin_amdgcn_udot4(b, b, 0u, false) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
+}
+
+template <int PNORM>
+__global__ void __launch_bounds__(256) k_dense2(WalkDev d)
+{
+    const int nblk = d.nbr * d.nbc;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)nblk * d.pairs) return;
+    const int pair = (int)(gid / nblk), blk = (int)(gid % nblk);
+    const int r0 = (blk / d.nbc) * 2, c0 = (blk % d.nbc) * 2;
+    const int pitch = d.pitch;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)r0 * pitch + c0;
+    const uint32_t a = (uint32_t)(*(const uint16_t*)ap) | ((uint32_t)(*(const uint16_t*)(ap + pitch)) << 16);
+    const unsigned aa = PNORM ? __builtin_amdgcn_udot4(a, a, 0u, false) : 0u;
+    const int maxr = d.H - 2 - 1, maxc = d.W - 2 - 1;
+    const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };
+    int pr = r0, pc = c0;
+    unsigned centre = cost2x2<PNORM>(a, aa, cur, pitch, clamp_ref(pr, maxr), clamp_ref(pc, maxc));
+    const int cap = 2 * (d.H + d.W) + 64;
+    bool overrun = false;
+    for (int it = 0;; ++it) {
+        unsigned best = centre;
+        int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rr = clamp_ref(pr + ldr[k], maxr), cc = clamp_ref(pc + ldc[k], maxc);
+            const unsigned c = cost2x2<PNORM>(a, aa, cur, pitch, rr, cc);
+            if (c < best) { best = c; br = rr; bc = cc; }
+        }
+        const bool done = (br == pr && bc == pc);
+        pr = br; pc = bc; centre = best;
+        if (done) break;
+        if (it > cap) { overrun = true; break; }
+    }
+    const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
+    unsigned best = centre;
+    int br = pr, bc = pc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rr = clamp_ref(pr + sdr[k], maxr), cc = clamp_ref(pc + sdc[k], maxc);
+        const unsigned c = cost2x2<PNORM>(a, aa, cur, pitch, rr, cc);
+        if (c < best) { best = c; br = rr; bc = cc; }
+    }
+    if (overrun) atomicExch(d.status, 1);
+    int32_t* o = d.mf + gid * 2;
+    o[0] = bc - c0; o[1] = br - r0;
+}
+
+}  // namespace
+
+int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
+{
+    *handled = false;
+    if (job.procedure == GME_SEARCH_EXHAUSTIVE) return GME_OK;
+    const int nbr = job.H / job.bs, nbc = job.W / job.bs;
+    if (nbr == 0 || nbc == 0 || job.pairs == 0) return GME_OK;
+    WalkDev d;
+    d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride; d.pairs = job.pairs;
+    d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw; d.procedure = job.procedure;
+    d.nbr = nbr; d.nbc = nbc; d.mf = job.mf; d.status = ctx->status;
+    const long long total = (long long)nbr * nbc * job.pairs;
+    if (job.bs == 16) {
+        const unsigned grid = (unsigned)((total + 3) / 4);
+        if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
+        else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
+    } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        if (job.pnorm == 0) hipLaunchKernelGGL(k_dense2<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
+        else hipLaunchKernelGGL(k_dense2<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
+    } else {
+        return GME_OK;
+    }
+    GME_HIP_TRY(hipGetLastError());
+    *handled = true;
+    return GME_OK;
+}

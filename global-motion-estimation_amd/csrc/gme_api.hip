@@ -42,7 +42,9 @@ extern "C" gme_ctx* gme_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->status, 256) != hipSuccess || hipMemset(ctx->status, 0, 256) != hipSuccess) {
+        hipMalloc((void**)&ctx->status, 256) != hipSuccess ||
+        hipMemsetAsync(ctx->status, 0, 256, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
         gme_set_error("gme_create: HIP initialisation failed on device %d: %s", device_id,
                       hipGetErrorString(hipGetLastError()));
         delete ctx;
@@ -166,7 +168,7 @@ int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out)
     return GME_OK;
 }
 
-int plane_alloc(Plane* p, int count, int H, int W)
+int plane_alloc(gme_ctx* ctx, Plane* p, int count, int H, int W)
 {
     p->H = H; p->W = W; p->count = count;
     p->pitch = round_up(W, 64);
@@ -178,7 +180,9 @@ int plane_alloc(Plane* p, int count, int H, int W)
         gme_set_error("out of device memory (%zu bytes of frames)", p->bytes());
         return GME_ERR_NOMEM;
     }
-    GME_HIP_TRY(hipMemset(p->ptr, 0, p->bytes() + p->pitch));
+    // on the context's stream: a null-stream memset would not be ordered against the
+    // kernels this (non-blocking) stream runs next and could land on top of their output
+    GME_HIP_TRY(hipMemsetAsync(p->ptr, 0, p->bytes() + p->pitch, ctx->stream));
     return GME_OK;
 }
 
@@ -334,7 +338,7 @@ extern "C" gme_seq* gme_seq_create(gme_ctx* ctx, int n_frames, int H, int W)
     gme_seq* s = new (std::nothrow) gme_seq();
     if (!s) return nullptr;
     s->ctx = ctx; s->N = n_frames; s->H = H; s->W = W;
-    if (plane_alloc(&s->level[2], n_frames, H, W) != GME_OK) { delete s; return nullptr; }
+    if (plane_alloc(ctx, &s->level[2], n_frames, H, W) != GME_OK) { delete s; return nullptr; }
     return s;
 }
 
@@ -344,6 +348,7 @@ static void free_fit(FitLevelBuf& f)
     if (f.model) hipFree(f.model);
     if (f.mask) hipFree(f.mask);
     if (f.diff) hipFree(f.diff);
+    if (f.list) hipFree(f.list);
     if (f.thr) hipFree(f.thr);
     if (f.sums) hipFree(f.sums);
     f = FitLevelBuf();
@@ -405,6 +410,13 @@ extern "C" int gme_seq_synth(gme_seq* s, uint64_t seed, int t0)
     }
     s->pyramids_valid = false;
     return launch_synth_frames(s->ctx, seed, t0, s->synth_canvas, s->level[2]);
+}
+
+extern "C" int gme_seq_invalidate(gme_seq* s)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    s->pyramids_valid = false;
+    return GME_OK;
 }
 
 extern "C" int gme_seq_read_frame(gme_seq* s, int level, int index, uint8_t* out)
@@ -481,6 +493,7 @@ static int alloc_fit(FitLevelBuf& f, int pairs, int h, int w, bool full)
         ok = ok && hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.mask, n) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.diff, n * sizeof(int32_t)) == hipSuccess;
+        if ((size_t)h * w * 16 > 64 * 1024) ok = ok && hipMalloc(&f.list, n * 16) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.thr, (size_t)pairs * sizeof(int32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.sums, (size_t)pairs * 15 * sizeof(double)) == hipSuccess;
     }
@@ -501,7 +514,7 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
     for (int l = 1; l >= 0; --l) {
         const Plane& src = s->level[l + 1];
         if (!s->level[l].ptr) {
-            rc = plane_alloc(&s->level[l], s->N, (src.H + 1) / 2, (src.W + 1) / 2);
+            rc = plane_alloc(ctx, &s->level[l], s->N, (src.H + 1) / 2, (src.W + 1) / 2);
             if (rc) return rc;
         }
     }
@@ -571,6 +584,7 @@ static int ensure_fit_mv(gme_seq* s)
     if (f.model) hipFree(f.model);
     if (f.mask) hipFree(f.mask);
     if (f.diff) hipFree(f.diff);
+    if (f.list) hipFree(f.list);
     if (f.thr) hipFree(f.thr);
     if (f.sums) hipFree(f.sums);
     f = FitLevelBuf();
@@ -578,6 +592,7 @@ static int ensure_fit_mv(gme_seq* s)
     const size_t n = (size_t)s->mv_pairs * f.h * f.w;
     if (hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&f.mask, n) != hipSuccess ||
         hipMalloc((void**)&f.diff, n * sizeof(int32_t)) != hipSuccess ||
+        ((size_t)f.h * f.w * 16 > 64 * 1024 && hipMalloc(&f.list, n * 16) != hipSuccess) ||
         hipMalloc((void**)&f.thr, (size_t)s->mv_pairs * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void**)&f.sums, (size_t)s->mv_pairs * 15 * sizeof(double)) != hipSuccess) {
         gme_set_error("out of device memory (fit buffers)");
@@ -621,7 +636,7 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
     GME_REQUIRE(drop <= n, GME_ERR_ARG, "outlier fraction %g out of range", outlier_fraction);
     GME_HIP_TRY(hipMemcpyAsync(dparams, params_in, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, level_H, level_W, f->model, f->mask, f->diff,
-                          f->thr, f->sums);
+                          f->thr, f->sums, f->list);
     if (rc) return rc;
     GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return ctx_finish(ctx);
@@ -663,7 +678,7 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
     GME_REQUIRE(bs >= 1 && h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
     if (!s->comp.ptr || s->comp.count != pairs) {
         plane_free(&s->comp);
-        rc = plane_alloc(&s->comp, pairs, s->H, s->W);
+        rc = plane_alloc(ctx, &s->comp, pairs, s->H, s->W);
         if (rc) return rc;
         if (s->sse) hipFree(s->sse);
         if (s->comp_params) hipFree(s->comp_params);

@@ -57,7 +57,7 @@ struct gme_ctx {
 
 int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);
 int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out);
-int plane_alloc(Plane* p, int count, int H, int W);
+int plane_alloc(gme_ctx* ctx, Plane* p, int count, int H, int W);
 void plane_free(Plane* p);
 
 struct FitLevelBuf {
@@ -66,6 +66,7 @@ struct FitLevelBuf {
     int16_t* model = nullptr;     // [P][h][w][2]
     uint8_t* mask = nullptr;      // [P][h][w]
     int32_t* diff = nullptr;      // [P][h][w] L1 distance gt vs model
+    void* list = nullptr;         // [P][h][w] int4 inlier list, only for fields too large for LDS
     int32_t* thr = nullptr;       // [P]
     double* sums = nullptr;       // [P][15]
 };
@@ -120,7 +121,7 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst);
 int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0);
 int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params,
                      int drop_count, int level_H, int level_W, int16_t* model, uint8_t* mask,
-                     int32_t* diff, int32_t* thr, double* sums);
+                     int32_t* diff, int32_t* thr, double* sums, void* list);
 int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out);
 int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride, int pairs, int H,
                       int W, int pitch, const int32_t* mf32, const double* params, int h, int w,

@@ -21,27 +21,57 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// Each thread produces 4 horizontally adjacent output pixels.  Interior threads read, per
+// source row, the 16 aligned bytes [2x-4, 2x+12) that hold the 11 taps 2x-2 .. 2x+8 (one
+// dword-aligned 16-byte load instead of 20 byte loads); border threads take the reflecting path.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long src_stride, int sH, int sW,
                                                   int spitch, uint8_t* dst, long long dst_stride, int dH,
                                                   int dW, int dpitch)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dW || y >= dH) return;
     const uint8_t* s = src + (long long)blockIdx.z * src_stride;
-    int cx[5], k[5] = { 1, 4, 6, 4, 1 };
+    uint8_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y * dpitch + x;
+    const int k[5] = { 1, 4, 6, 4, 1 };
+    int acc[4] = { 0, 0, 0, 0 };
+    const bool interior = x >= 4 && 2 * x + 12 <= sW && x + 4 <= dW;
+    if (interior) {
 #pragma unroll
-    for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * x + d - 2, sW);
-    int acc = 0;
+        for (int dy = 0; dy < 5; ++dy) {
+            const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch + 2 * x - 4;
+            const u32x4_a4 v = *(const u32x4_a4*)row;
+            const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+            int t[16];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-        const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch;
-        int h = 0;
+            for (int b = 0; b < 16; ++b) t[b] = (wds[b >> 2] >> (8 * (b & 3))) & 0xFF;
 #pragma unroll
-        for (int d = 0; d < 5; ++d) h += k[d] * row[cx[d]];
-        acc += k[dy] * h;
+            for (int p = 0; p < 4; ++p) {                  // taps of output p start at byte 2 + 2p
+                const int h = t[2 + 2 * p] + 4 * t[3 + 2 * p] + 6 * t[4 + 2 * p] + 4 * t[5 + 2 * p] + t[6 + 2 * p];
+                acc[p] += k[dy] * h;
+            }
+        }
+        *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) |
+                        ((uint32_t)((acc[2] + 128) >> 8) << 16) | ((uint32_t)((acc[3] + 128) >> 8) << 24);
+        return;
     }
-    dst[(long long)blockIdx.z * dst_stride + (long long)y * dpitch + x] = (uint8_t)((acc + 128) >> 8);
+    for (int p = 0; p < 4 && x + p < dW; ++p) {
+        int cx[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * (x + p) + d - 2, sW);
+        int a = 0;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch;
+            int h = 0;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) h += k[d] * row[cx[d]];
+            a += k[dy] * h;
+        }
+        o[p] = (uint8_t)((a + 128) >> 8);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -100,8 +130,9 @@ __global__ void __launch_bounds__(256) k_affine_field(const double* params, int 
 __global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h, int w, const double* params,
                                                     int drop, double wgt, int16_t* model_all,
                                                     uint8_t* mask_all, int32_t* diff_all, int32_t* thr_all,
-                                                    double* sums_all)
+                                                    double* sums_all, int4* list_all, int list_lds)
 {
+    extern __shared__ int4 dyn_lds[];
     __shared__ unsigned hist[256];
     __shared__ unsigned sel_prefix, sel_rank;
     const int n = h * w;
@@ -147,29 +178,52 @@ __global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h,
         __syncthreads();
     }
     const int thr = (int)sel_prefix;
-    for (int k = threadIdx.x; k < n; k += 256) mask[k] = diff[k] > thr;      // strict, motion.py:244
     if (threadIdx.x == 0) thr_all[pair] = thr;
+
+    // mask (strict >, motion.py:244) and ordered compaction of the inliers: entry e of the
+    // list is the e-th inlier in row-major order, stored as (4i, 4j, gt0, gt1)
+    __shared__ int wave_count[4];
+    __shared__ int list_base;
+    int4* list = list_lds ? (int4*)dyn_lds : list_all + (long long)pair * n;
+    if (threadIdx.x == 0) list_base = 0;
     __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int k = k0 + threadIdx.x;
+        bool inl = false;
+        if (k < n) {
+            const bool out = diff[k] > thr;
+            mask[k] = out;
+            inl = !out;
+        }
+        const unsigned long long bal = __ballot(inl);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wave_count[wv] = __popcll(bal);
+        __syncthreads();
+        int off = list_base;
+        for (int q = 0; q < wv; ++q) off += wave_count[q];
+        if (inl) {
+            const int i = k / w, j = k - i * w;
+            list[off + __popcll(bal & ((1ull << lane) - 1))] = make_int4(i * 4, j * 4, gt[2 * k], gt[2 * k + 1]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) list_base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        __syncthreads();
+    }
+    const int m = list_base;
 
     // sequential float64 sums over inliers in row-major order (motion.py:248-261,266-279);
-    // twelve independent chains, one per lane: F00 F01 F02 F11 F12 F22 | Sx0..2 | Sy0..2
+    // twelve independent chains, one per lane: F00 F01 F02 F11 F12 F22 | Sx0..2 | Sy0..2.
+    // The list makes the loop branch-free, so its loads pipeline ahead of the add chain.
     if (threadIdx.x < 12) {
         const int c = threadIdx.x;
         const int fa[6] = { 0, 0, 0, 1, 1, 2 }, fb[6] = { 0, 1, 2, 1, 2, 2 };
         const int a = c < 6 ? fa[c] : (c - 6) % 3;
-        const int b = c < 6 ? fb[c] : -1;
-        const int ch = c < 9 ? 0 : 1;
+        const int b = c < 6 ? fb[c] : (c < 9 ? 3 : 4);          // 3, 4: the two motion-vector channels
         double acc = 0.0;
-        int k = 0;
-        for (int i = 0; i < h; ++i) {
-            const double x = (double)(i * 4);                 // literal 4, motion.py:254
-            for (int j = 0; j < w; ++j, ++k) {
-                if (mask[k]) continue;
-                const double y = (double)(j * 4);
-                const double va = a == 0 ? 1.0 : (a == 1 ? x : y);
-                const double vb = b < 0 ? (double)gt[2 * k + ch] : (b == 0 ? 1.0 : (b == 1 ? x : y));
-                acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(va, vb), wgt));
-            }
+        for (int e = 0; e < m; ++e) {
+            const int4 v = list[e];
+            const int vi[5] = { 1, v.x, v.y, v.z, v.w };         // literal 4 already applied (motion.py:254-255)
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)vi[a], (double)vi[b]), wgt));
         }
         double* s = sums_all + (long long)pair * 15;
         if (c < 6) { s[fa[c] * 3 + fb[c]] = acc; s[fb[c] * 3 + fa[c]] = acc; }
@@ -182,43 +236,104 @@ __global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h,
 // `cur` (utils.py:109).  The field is either given (mf32) or evaluated from the affine
 // parameters per block (results.py:52-54).
 // ---------------------------------------------------------------------------
+constexpr int COMP_ROWS = 32;      // rows per workgroup: one atomic per 256 x 32 tile
+
+// Each thread owns 4 horizontally adjacent pixels of COMP_ROWS/4 rows.  When the block size is a
+// multiple of 4 the four pixels share one vector; if their sources lie inside the frame they
+// are gathered with two aligned dword loads + v_alignbyte and stored as one dword.
 __global__ void __launch_bounds__(256) k_compensate(const uint8_t* frames, long long frame_stride, int H, int W,
                                                      int pitch, const int32_t* mf32, const double* params, int h,
                                                      int w, uint8_t* out, long long out_stride, int out_pitch,
                                                      const uint8_t* cur, long long cur_stride,
                                                      unsigned long long* sse)
 {
+    __shared__ unsigned part[4];
     const int pair = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int ybase = blockIdx.y * COMP_ROWS + (threadIdx.x >> 6);
     const uint8_t* f = frames + (long long)pair * frame_stride;
-    unsigned long long err = 0;
-    if (x < W && y < H) {
-        const int bs = H / h;                           // height only, motion.py:303
-        const int i = y / bs, j = x / bs;
-        uint8_t v = f[(long long)y * pitch + x];
-        if (i < h && j < w) {
-            int d0, d1;
-            if (mf32) {
-                const int32_t* m = mf32 + (((long long)pair * h + i) * w + j) * 2;
-                d0 = m[0]; d1 = m[1];
-            } else {
-                const double* p = params + (long long)pair * 6;
-                d0 = model_component(p[0], p[1], p[2], i, j);
-                d1 = model_component(p[3], p[4], p[5], i, j);
-            }
-            const long long sy = (long long)y - d1, sx = (long long)x - d0;
-            if (sy >= 0 && sx >= 0 && sy < H && sx < W) v = f[sy * pitch + sx];
+    const int bs = H / h;                               // height only, motion.py:303
+    unsigned err = 0;
+    if (x < W) {
+        double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+        if (!mf32) {
+            const double* p = params + (long long)pair * 6;
+            p0 = p[0]; p1 = p[1]; p2 = p[2]; p3 = p[3]; p4 = p[4]; p5 = p[5];
         }
-        out[(long long)pair * out_stride + (long long)y * out_pitch + x] = v;
-        if (cur) {
-            const int df = (int)cur[(long long)pair * cur_stride + (long long)y * pitch + x] - (int)v;
-            err = (unsigned)(df * df);
+        const bool quad = (bs & 3) == 0 && x + 4 <= W;  // 4 pixels, one block column
+        const int j = x / bs;
+        int last_i = -1, d0 = 0, d1 = 0;
+        const int yend = min(H, (int)(blockIdx.y + 1) * COMP_ROWS);
+        for (int y = ybase; y < yend; y += 4) {
+            const int i = y / bs;
+            uint8_t* o = out + (long long)pair * out_stride + (long long)y * out_pitch + x;
+            const uint8_t* c = cur ? cur + (long long)pair * cur_stride + (long long)y * pitch + x : nullptr;
+            if (quad) {
+                uint32_t v = *(const uint32_t*)(f + (long long)y * pitch + x);
+                if (i < h && j < w) {
+                    if (i != last_i) {                  // the vector changes only at block-row borders
+                        last_i = i;
+                        if (mf32) {
+                            const int32_t* m = mf32 + (((long long)pair * h + i) * w + j) * 2;
+                            d0 = m[0]; d1 = m[1];
+                        } else {
+                            d0 = model_component(p0, p1, p2, i, j);
+                            d1 = model_component(p3, p4, p5, i, j);
+                        }
+                    }
+                    const long long sy = (long long)y - d1, sx = (long long)x - d0;
+                    if (sy >= 0 && sy < H) {
+                        if (sx >= 0 && sx + 4 <= W) {
+                            const uint8_t* sp = f + sy * pitch + (sx & ~3ll);
+                            const uint32_t lo = *(const uint32_t*)sp, hi = *(const uint32_t*)(sp + 4);
+                            v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sx & 3u);
+                        } else {                        // straddles the left/right frame edge: per pixel
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (sx + q >= 0 && sx + q < W)
+                                    v = (v & ~(0xFFu << (8 * q))) | ((uint32_t)f[sy * pitch + sx + q] << (8 * q));
+                        }
+                    }
+                }
+                *(uint32_t*)o = v;
+                if (c) {
+                    const uint32_t cv = *(const uint32_t*)c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int df = (int)((cv >> (8 * q)) & 0xFF) - (int)((v >> (8 * q)) & 0xFF);
+                        err += (unsigned)(df * df);
+                    }
+                }
+            } else {
+                for (int q = 0; q < 4 && x + q < W; ++q) {
+                    const int jq = (x + q) / bs;
+                    uint8_t v = f[(long long)y * pitch + x + q];
+                    if (i < h && jq < w) {
+                        int e0, e1;
+                        if (mf32) {
+                            const int32_t* m = mf32 + (((long long)pair * h + i) * w + jq) * 2;
+                            e0 = m[0]; e1 = m[1];
+                        } else {
+                            e0 = model_component(p0, p1, p2, i, jq);
+                            e1 = model_component(p3, p4, p5, i, jq);
+                        }
+                        const long long sy = (long long)y - e1, sx = (long long)x + q - e0;
+                        if (sy >= 0 && sx >= 0 && sy < H && sx < W) v = f[sy * pitch + sx];
+                    }
+                    o[q] = v;
+                    if (c) { const int df = (int)c[q] - (int)v; err += (unsigned)(df * df); }
+                }
+            }
         }
     }
-    if (sse) {
-        for (int m = 32; m > 0; m >>= 1) err += (unsigned long long)__shfl_xor((int)err, m, 64);
-        if ((threadIdx.x & 63) == 0 && err) atomicAdd(&sse[pair], err);
+    if (sse) {                                          // integer sums: order independent, deterministic
+        for (int m = 32; m > 0; m >>= 1) err += (unsigned)__shfl_xor((int)err, m, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = err;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+            if (t) atomicAdd(&sse[pair], t);
+        }
     }
 }
 
@@ -245,7 +360,7 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
 {
     GME_REQUIRE(dst.H == (src.H + 1) / 2 && dst.W == (src.W + 1) / 2 && dst.count == src.count, GME_ERR_ARG,
                 "pyrdown: destination shape mismatch");
-    const dim3 grid((dst.W + 63) / 64, (dst.H + 3) / 4, src.count);
+    const dim3 grid((dst.W + 255) / 256, (dst.H + 3) / 4, src.count);
     hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
                        src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
     GME_HIP_TRY(hipGetLastError());
@@ -270,12 +385,15 @@ int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, in
 
 int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params, int drop,
                      int level_H, int level_W, int16_t* model, uint8_t* mask, int32_t* diff, int32_t* thr,
-                     double* sums)
+                     double* sums, void* list)
 {
     if (pairs == 0) return GME_OK;
     const double wgt = 1.0 / ((double)level_H * (double)level_W);      // motion.py:250
-    hipLaunchKernelGGL(k_fit_level, dim3(pairs), dim3(256), 0, ctx->stream, gt, h, w, params, drop, wgt, model, mask,
-                       diff, thr, sums);
+    // inlier list: LDS when it fits beside a second resident workgroup, else the global buffer
+    const size_t need = (size_t)h * w * sizeof(int4);
+    const int in_lds = need <= 64 * 1024;
+    hipLaunchKernelGGL(k_fit_level, dim3(pairs), dim3(256), in_lds ? need : 0, ctx->stream, gt, h, w, params, drop, wgt,
+                       model, mask, diff, thr, sums, (int4*)list, in_lds);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }
@@ -286,7 +404,7 @@ int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride,
 {
     if (pairs == 0) return GME_OK;
     if (sse) GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
-    const dim3 grid((W + 63) / 64, (H + 3) / 4, pairs);
+    const dim3 grid((W + 255) / 256, (H + COMP_ROWS - 1) / COMP_ROWS, pairs);
     hipLaunchKernelGGL(k_compensate, grid, dim3(256), 0, ctx->stream, frames, (long long)frame_stride, H, W, pitch,
                        mf32, params, h, w, out, (long long)out_stride, out_pitch, cur, (long long)cur_stride, sse);
     GME_HIP_TRY(hipGetLastError());

@@ -34,6 +34,18 @@ def _solve(sums):
     return np.concatenate([ax, ay])
 
 
+def _solve_batch(sums):
+    """`_solve` for float64[P, 15]: stacked ``inv``/``matmul`` run the same LAPACK/BLAS routine
+    per matrix, so the rows equal the per-pair calls bit for bit (tests/test_host.py checks)."""
+    sums = np.asarray(sums, dtype=np.float64)
+    if len(sums) == 0:
+        return np.zeros((0, 6))
+    finv = np.linalg.inv(sums[:, :9].reshape(-1, 3, 3))
+    ax = np.matmul(finv, sums[:, 9:12, None])[:, :, 0]
+    ay = np.matmul(finv, sums[:, 12:15, None])[:, :, 0]
+    return np.concatenate([ax, ay], axis=1)
+
+
 def _fit_pair(previous, current, old_parameters, fraction):
     ctx = _native.default_context()
     seq = _native.Sequence.from_frames(ctx, [previous, current])
@@ -95,10 +107,9 @@ def estimate_sequence(seq, frame_distance=1, procedure=3, search_window=2):
     frac = float(MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
     params = seq.gme_begin(frame_distance, int(BBME_BLOCK_SIZE), procedure, search_window)   # float32[P,6]
     for level in (1, 2):
-        for p in params:
-            parameter_projection(p)
-        sums = seq.gme_fit(level, params.astype(np.float64), frac)
-        params = np.stack([_solve(s) for s in sums]) if len(sums) else np.zeros((0, 6))
+        params[:, 0] = params[:, 0] * 2            # parameter_projection, in the array's own dtype
+        params[:, 3] = params[:, 3] * 2
+        params = _solve_batch(seq.gme_fit(level, params.astype(np.float64), frac))
     return params
 
 

@@ -102,6 +102,8 @@ GME_API int gme_seq_upload(gme_seq *seq, int first, int count, const uint8_t *fr
                    int64_t frame_stride);
 /* deterministic synthetic frames t0 .. t0+N-1 generated on the device */
 GME_API int gme_seq_synth(gme_seq *seq, uint64_t seed, int t0);
+/* mark the pyramid levels stale (upload and synth do so themselves) */
+GME_API int gme_seq_invalidate(gme_seq *seq);
 /* level 2 = full resolution, 1 and 0 = pyramid levels (valid after gme_seq_gme_begin) */
 GME_API int gme_seq_read_frame(gme_seq *seq, int level, int index, uint8_t *out);
 

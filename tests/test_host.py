@@ -86,6 +86,29 @@ def test_solve_matches_oracle_and_raises_on_singular(golden):
     assert d.shape == (2,) and d[0] == 1 + 1.5 + 1 and d[1] == 7
 
 
+def test_batched_solve_equals_per_pair_solve(golden):
+    """estimate_sequence solves all pairs with one stacked inv/matmul; it must equal the
+    per-pair calls the reference makes (motion.py:262-264,280-282) bit for bit."""
+    import motion
+    g = golden("g4_gme")
+    rng = np.random.default_rng(3)
+    rows = []
+    for tag in ("synth720", "race", "pan240", "dp", "small", "bs12"):
+        for lvl in (1, 2):
+            rows.append(np.concatenate([g["%s_l%d_F" % (tag, lvl)].reshape(9), g["%s_l%d_Sx" % (tag, lvl)],
+                                        g["%s_l%d_Sy" % (tag, lvl)]]))
+    for _ in range(500):
+        a = rng.normal(size=(3, 3))
+        rows.append(np.concatenate([(a @ a.T * rng.uniform(1e-3, 1e3)).reshape(9), rng.normal(size=6)]))
+    rows = np.array(rows)
+    batch = motion._solve_batch(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(batch[k], motion._solve(r)), k
+    assert motion._solve_batch(np.zeros((0, 15))).shape == (0, 6)
+    with pytest.raises(np.linalg.LinAlgError):
+        motion._solve_batch(np.zeros((2, 15)))
+
+
 def test_shard_ranges_cover_pairs_once():
     import sequence
     for n in (0, 1, 5, 8, 1999):
