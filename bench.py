@@ -38,6 +38,9 @@ CONFIGS = {
     # full GME: procedure/pnorm fields unused (the reference hard-codes diamond + MSE, motion.py:27,224)
     "gme720": (480, 720, 16, 2, -1, 1, 1234, "720x480 full multiscale affine GME (3-level pyramid + diamond BBME + "
                "outlier mask + compensate + PSNR), BASELINE configs[2]"),
+    "exh1080mse": (1080, 1920, 16, 32, 0, 1, 4321, "1920x1080 synthetic luma, bs=16 sw=32 exhaustive MSE"),
+    "gme1080exh": (1080, 1920, 16, 32, -2, 1, 4321, "1920x1080 synthetic, bs=16 sw=32 exhaustive MSE + affine fit "
+                   "(BASELINE configs[3]: GME with exhaustive BBME at levels 1-2) + compensate"),
     "gme1080": (1080, 1920, 16, 2, -1, 1, 2000, "1920x1080 synthetic sequence, diamond-search GME + compensate, "
                 "BASELINE configs[4] per-GPU shard"),
 }
@@ -149,7 +152,7 @@ def main():
             # motion.global_motion_estimation + results.py:52-59,109 for every resident pair;
             # frames change between videos, so the pyramids are rebuilt inside the step
             seq.invalidate_pyramids()
-            params = motion.estimate_sequence(seq, 1)
+            params = motion.estimate_sequence(seq, 1, 0, sw) if proc == -2 else motion.estimate_sequence(seq, 1)
             last["params"], last["sse"] = params, seq.compensate(1, int(motion.BBME_BLOCK_SIZE), params)
     else:
         def step():

@@ -21,6 +21,8 @@
 // XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
 // handles pair (b/8/WPP)*8 + b%8 -- all blocks of one frame pair run on one XCD and
 // the pair's two frames are pulled into that XCD's L2 once.
+#include <stdlib.h>
+
 #include "gme_internal.h"
 
 namespace {
@@ -33,12 +35,38 @@ struct FastDev {
     int nbr, nbc, nb, wg_per_row, wg_per_pair;
     int pitch_dw, win_rows;
     int32_t* mf;
+    const uint32_t* sqbox;        // MSE: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
+    long long sqbox_stride;       // elements between consecutive planes
 };
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
 
+// ---- stage the search window (coalesced dword loads; out-of-frame -> 0) ----
+// thread -> one dword column and every `rstep`-th row: no div/mod inside the loop
+__device__ __forceinline__ void stage_window(const FastDev& d, uint32_t* win, const uint8_t* cur, int bcol0, int r0)
+{
+    const int gx0 = bcol0 * 16 - d.sw;             // multiple of 4 (sw % 4 == 0)
+    const int gy0 = r0 - d.sw;
+    const int rstep = blockDim.x / d.pitch_dw;
+    const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
+    const int gx = gx0 + 4 * dw;
+    const bool colok = gx >= 0 && gx < d.pitch;
+    if (row0 < rstep) {
+        const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
+        const long long sstep = (long long)rstep * d.pitch;
+        uint32_t* dst = win + row0 * d.pitch_dw + dw;
+        const int dstep = rstep * d.pitch_dw;
+        for (int row = row0; row < d.win_rows; row += rstep, src += sstep, dst += dstep) {
+            const int gy = gy0 + row;
+            uint32_t v = 0;
+            if (colok && gy >= 0 && gy < d.H) v = *(const uint32_t*)src;
+            *dst = v;
+        }
+    }
+}
+
 template <int R>
-__global__ void k_exh_qsad16(FastDev d)
+__global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
 {
     extern __shared__ uint32_t win[];                 // [win_rows][pitch_dw]
     constexpr int NW = R + 3;                          // 64-bit window pairs per lane and row
@@ -52,28 +80,7 @@ __global__ void k_exh_qsad16(FastDev d)
     const int NC = 2 * d.sw + 16;
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
 
-    // ---- stage the search window (coalesced dword loads; out-of-frame -> 0) ----
-    // thread -> one dword column and every `rstep`-th row: no div/mod inside the loop
-    {
-        const int gx0 = bcol0 * 16 - d.sw;             // multiple of 4 (sw % 4 == 0)
-        const int gy0 = r0 - d.sw;
-        const int rstep = blockDim.x / d.pitch_dw;
-        const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
-        const int gx = gx0 + 4 * dw;
-        const bool colok = gx >= 0 && gx < d.pitch;
-        if (row0 < rstep) {
-            const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
-            const long long sstep = (long long)rstep * d.pitch;
-            uint32_t* dst = win + row0 * d.pitch_dw + dw;
-            const int dstep = rstep * d.pitch_dw;
-            for (int row = row0; row < d.win_rows; row += rstep, src += sstep, dst += dstep) {
-                const int gy = gy0 + row;
-                uint32_t v = 0;
-                if (colok && gy >= 0 && gy < d.H) v = *(const uint32_t*)src;
-                *dst = v;
-            }
-        }
-    }
+    stage_window(d, win, cur, bcol0, r0);
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -173,6 +180,170 @@ __global__ void k_exh_qsad16(FastDev d)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Exhaustive MSE, bs = 16:  SSD = sum(A^2) + sum(B^2) - 2 sum(A.B).
+//   sum(A.B)  v_dot4_u32_u8 against the SGPR anchor, same lane mapping as k_exh_qsad16; the three
+//             byte-shifted copies of each window dword come from v_alignbyte_b32 (shared by the R
+//             anchor rows that use them);
+//   sum(B^2)  one lookup per candidate in the per-frame table built by k_sqbox16_* (every candidate
+//             position is shared by up to nine macroblocks, so the table is built once per frame);
+//   sum(A^2)  64 v_dot4 + a wave reduction, once per block.
+// All terms are exact integers < 2^26 (bs = 16), equal to the reference's float32 sums (bbme.py:94).
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
+{
+    extern __shared__ uint32_t win[];
+    constexpr int NW = R + 4;                          // window dwords per lane and row
+    const int b = blockIdx.x;
+    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    if (pair >= d.pairs) return;
+    const int wg = (b >> 3) % d.wg_per_pair;
+    const int brow = wg / d.wg_per_row;
+    const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+    const int r0 = brow * 16;
+    const int NC = 2 * d.sw + 16;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    stage_window(d, win, cur, bcol0, r0);
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bcol = bcol0 + wave;
+    if (bcol >= d.nbc) return;
+    const int c0 = bcol * 16;
+    const int lane = threadIdx.x & 63;
+    const int prow = lane >> 2, q = lane & 3;
+
+    const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+    const uint32_t* anchor = (const uint32_t*)aptr;
+    const int apitch = d.pitch >> 2;
+    uint32_t A[16][4];
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+    // sum of squares of the anchor: lane l takes dword l of the block
+    uint32_t a2;
+    {
+        const uint32_t mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        a2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) a2 += (uint32_t)__shfl_xor((int)a2, m, 64);
+    }
+
+    uint32_t acc[R][R][4];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][k][e] = 0;
+
+    const uint32_t* lrow = win + (prow * R) * d.pitch_dw + wave * 4 + q * R;
+#pragma unroll
+    for (int t = 0; t < R + 15; ++t) {
+        uint32_t w[NW];
+#pragma unroll
+        for (int s = 0; s < NW; ++s) w[s] = lrow[t * d.pitch_dw + s];
+        uint32_t sh[NW - 1][4];                        // sh[s][e] = bytes 4s+e .. 4s+e+3 of the row
+#pragma unroll
+        for (int s = 0; s < NW - 1; ++s) {
+            sh[s][0] = w[s];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) sh[s][e] = __builtin_amdgcn_alignbyte(w[s + 1], w[s], (uint32_t)e);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int a = t - i;
+            if (a < 0 || a > 15) continue;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][k][e] = __builtin_amdgcn_udot4(sh[k + j][e], A[a][j], acc[i][k][e], false);
+        }
+        // Pin this row's dot products before the next row's: an empty asm that "modifies" every
+        // accumulator.  Without it instruction selection linearises the unrolled body one
+        // accumulator chain at a time, keeps all 18 rows of shifted dwords live (> 256 VGPRs,
+        // spills) and pads the dependent v_dot4 chain with s_nops.
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(acc[i][k][e]));
+    }
+
+    // ---- costs and the first minimum in scan order (column index outer, row index inner) ----
+    const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
+    const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
+    const uint32_t* sq = d.sqbox + (long long)pair * d.sqbox_stride;
+    uint32_t bcost = 0xFFFFFFFFu;
+    int blocal = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < R; ++i) {              // local scan order: (4k+e) outer, i inner
+                const int ri = prow * R + i, ci = q * 4 * R + 4 * k + e;
+                if (ri >= lo_r && ri <= hi_r && ci >= lo_c && ci <= hi_c) {
+                    const uint32_t b2 = sq[(long long)(r0 - d.sw + ri) * d.pitch + (c0 - d.sw + ci)];
+                    const uint32_t cost = a2 + b2 - 2u * acc[i][k][e];
+                    if (cost < bcost) { bcost = cost; blocal = (4 * k + e) * R + i; }
+                }
+            }
+    unsigned long long best = ~0ull;
+    if (bcost != 0xFFFFFFFFu) {
+        const int ce = blocal / R, i = blocal - ce * R;
+        best = ((unsigned long long)bcost << 13) | (unsigned)((q * 4 * R + ce) * NC + prow * R + i);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, m, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), m, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o < best ? o : best;
+    }
+    if (lane == 0) {
+        const int idx = (int)(best & 0x1FFF);
+        const int ci = idx / NC, ri = idx - ci * NC;
+        int32_t* o = d.mf + (((long long)pair * d.nbr + brow) * d.nbc + bcol) * 2;
+        o[0] = ci - d.sw;
+        o[1] = ri - d.sw;
+    }
+}
+
+// 16x16 box sums of squares, two separable passes over one plane stack.
+__global__ void __launch_bounds__(256) k_sqbox16_rows(const uint8_t* src, long long src_stride, int H, int W, int pitch,
+                                                      uint32_t* dst, long long dst_stride)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x > W - 16 || y >= H) return;
+    const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y * pitch + x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (uint32_t)p[k] * p[k];
+    dst[(long long)blockIdx.z * dst_stride + (long long)y * pitch + x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_sqbox16_cols(const uint32_t* rows, uint32_t* dst, long long stride, int H, int W,
+                                                      int pitch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x > W - 16 || y > H - 16) return;
+    const uint32_t* p = rows + (long long)blockIdx.z * stride + (long long)y * pitch + x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += p[(long long)k * pitch];
+    dst[(long long)blockIdx.z * stride + (long long)y * pitch + x] = s;
+}
+
 // LDS row pitch (in dwords) that keeps the per-row ds_read2_b32 of a half-wave on
 // distinct banks: lanes (prow 0..7, q 0..3) read dword (prow*R + t)*pitch + q*R + s.
 int pick_pitch_dw(int need, int R)
@@ -197,7 +368,9 @@ int pick_pitch_dw(int need, int R)
 int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
 {
     *handled = false;
-    if (job.procedure != GME_SEARCH_EXHAUSTIVE || job.bs != 16 || job.pnorm != GME_NORM_MAE) return GME_OK;
+    if (job.procedure != GME_SEARCH_EXHAUSTIVE || job.bs != 16) return GME_OK;
+    const bool mse = job.pnorm == GME_NORM_MSE;
+    if (mse && (job.sqbox_cur == nullptr || getenv("GME_FORCE_GENERIC"))) return GME_OK;
     if (job.sw < 0 || job.sw % 4 != 0) return GME_OK;
     const int NC = 2 * job.sw + 16;
     const int R = (NC + 15) / 16;
@@ -210,6 +383,7 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
+    d.sqbox = job.sqbox_cur; d.sqbox_stride = job.sqbox_stride;
     // waves per workgroup: prefer an exact divisor of the block-row length
     int nb = 4;
     for (int cand : {5, 4, 6, 3}) if (nbc % cand == 0) { nb = cand; break; }
@@ -219,12 +393,24 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.wg_per_pair = d.wg_per_row * nbr;
     d.win_rows = 16 * R + 15;                          // rows a lane may touch: prow*R + t, t < R+15
     // bytes a lane may touch in a row: wave*16 + q*4R + 4*(R+3) + 8  (last 64-bit pair)
-    const int need_dw = (nb - 1) * 4 + 3 * R + (R + 2) + 2;
+    const int need_dw = (nb - 1) * 4 + 3 * R + (R + 2) + 2;      // also covers k_exh_dot16's R + 4 dwords
     d.pitch_dw = pick_pitch_dw(need_dw, R);
     const size_t lds = (size_t)d.win_rows * d.pitch_dw * 4;
     const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
     GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
     const dim3 grid((unsigned)groups), block(64 * nb);
+    if (mse) {
+        switch (R) {
+        case 1: hipLaunchKernelGGL(k_exh_dot16<1>, grid, block, lds, ctx->stream, d); break;
+        case 2: hipLaunchKernelGGL(k_exh_dot16<2>, grid, block, lds, ctx->stream, d); break;
+        case 3: hipLaunchKernelGGL(k_exh_dot16<3>, grid, block, lds, ctx->stream, d); break;
+        case 4: hipLaunchKernelGGL(k_exh_dot16<4>, grid, block, lds, ctx->stream, d); break;
+        default: hipLaunchKernelGGL(k_exh_dot16<5>, grid, block, lds, ctx->stream, d); break;
+        }
+        GME_HIP_TRY(hipGetLastError());
+        *handled = true;
+        return GME_OK;
+    }
     switch (R) {
     case 1: hipLaunchKernelGGL(k_exh_qsad16<1>, grid, block, lds, ctx->stream, d); break;
     case 2: hipLaunchKernelGGL(k_exh_qsad16<2>, grid, block, lds, ctx->stream, d); break;
@@ -235,4 +421,30 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
     return GME_OK;
+}
+
+// 16x16 box sums of squares for `count` planes: `tmp` and `out` are uint32 stacks with the
+// frame's pitch (elements) and `stride` elements between planes.
+int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
+                   uint32_t* tmp, uint32_t* out, long long stride)
+{
+    if (count == 0 || H < 16 || W < 16) return GME_OK;
+    for (int first = 0; first < count; first += 32768) {
+        const int n = count - first < 32768 ? count - first : 32768;
+        const dim3 grid((W - 15 + 63) / 64, (H + 3) / 4, n);
+        hipLaunchKernelGGL(k_sqbox16_rows, grid, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W,
+                           pitch, tmp + first * stride, stride);
+        hipLaunchKernelGGL(k_sqbox16_cols, grid, dim3(256), 0, ctx->stream, tmp + first * stride, out + first * stride,
+                           stride, H, W, pitch);
+    }
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+bool bbme_wants_sqbox(int bs, int sw, int procedure, int pnorm)
+{
+    if (procedure != GME_SEARCH_EXHAUSTIVE || bs != 16 || pnorm != GME_NORM_MSE) return false;
+    if (sw < 0 || sw % 4 != 0) return false;
+    const int NC = 2 * sw + 16;
+    return (NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC");
 }

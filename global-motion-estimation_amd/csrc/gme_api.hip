@@ -219,6 +219,8 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     Carver c;
     const size_t o_prev = c.take(plane + pitch), o_cur = c.take(plane + pitch);
     const size_t o_mf = c.take((size_t)h * w * 2 * sizeof(int32_t));
+    const bool want_sq = bbme_wants_sqbox(block_size, search_window, procedure, pnorm);
+    const size_t o_sq = c.take(want_sq ? plane * 4 : 0), o_sqtmp = c.take(want_sq ? plane * 4 : 0);
     void* base = nullptr;
     rc = ctx_scratch(ctx, c.off, &base);
     if (rc) return rc;
@@ -231,6 +233,11 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     job.H = H; job.W = W; job.pitch = pitch;
     job.bs = block_size; job.sw = search_window; job.procedure = procedure; job.pnorm = pnorm;
     job.mf = (int32_t*)(b + o_mf); job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+    if (want_sq) {
+        rc = launch_sqbox16(ctx, b + o_cur, 0, 1, H, W, pitch, (uint32_t*)(b + o_sqtmp), (uint32_t*)(b + o_sq), 0);
+        if (rc) return rc;
+        job.sqbox_cur = (const uint32_t*)(b + o_sq);
+    }
     rc = launch_bbme(ctx, job);
     if (rc) return rc;
     GME_HIP_TRY(hipMemcpyAsync(mf_out, b + o_mf, (size_t)h * w * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -365,7 +372,8 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     if (s->mv_params) hipFree(s->mv_params);
     plane_free(&s->comp);
     if (s->mv) hipFree(s->mv);
-    if (s->sqbox) hipFree(s->sqbox);
+    for (int l = 0; l < 3; ++l) if (s->sqbox[l]) hipFree(s->sqbox[l]);
+    if (s->sqtmp) hipFree(s->sqtmp);
     if (s->params0) hipFree(s->params0);
     if (s->params_in) hipFree(s->params_in);
     if (s->sse) hipFree(s->sse);
@@ -387,6 +395,7 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
         GME_HIP_TRY(hipMemcpy2DAsync(p.at(first + i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
                                      hipMemcpyHostToDevice, s->ctx->stream));
     s->pyramids_valid = false;
+    s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // the host buffer may be reused on return
     return GME_OK;
 }
@@ -409,6 +418,7 @@ extern "C" int gme_seq_synth(gme_seq* s, uint64_t seed, int t0)
         s->synth_seed = seed; s->synth_valid = true;
     }
     s->pyramids_valid = false;
+    s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     return launch_synth_frames(s->ctx, seed, t0, s->synth_canvas, s->level[2]);
 }
 
@@ -416,6 +426,7 @@ extern "C" int gme_seq_invalidate(gme_seq* s)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     s->pyramids_valid = false;
+    s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     return GME_OK;
 }
 
@@ -446,6 +457,23 @@ static int ensure(T** ptr, size_t* have, size_t want_bytes)
     return GME_OK;
 }
 
+// box table of squares for every frame of one pyramid level (exhaustive MSE fast path)
+static int seq_sqbox(gme_seq* s, int level)
+{
+    const Plane& p = s->level[level];
+    const size_t bytes = (size_t)p.stride * p.count * sizeof(uint32_t);
+    int rc = ensure(&s->sqbox[level], &s->sqbox_bytes[level], bytes);
+    if (rc) return rc;
+    rc = ensure(&s->sqtmp, &s->sqtmp_bytes, bytes);
+    if (rc) return rc;
+    if (!s->sqbox_valid[level]) {
+        rc = launch_sqbox16(s->ctx, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqtmp, s->sqbox[level], p.stride);
+        if (rc) return rc;
+        s->sqbox_valid[level] = true;
+    }
+    return GME_OK;
+}
+
 extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, int pnorm)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
@@ -465,6 +493,12 @@ extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, i
     job.H = s->H; job.W = s->W; job.pitch = p.pitch;
     job.bs = bs; job.sw = sw; job.procedure = procedure; job.pnorm = pnorm;
     job.mf = s->mv; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+    if (bbme_wants_sqbox(bs, sw, procedure, pnorm)) {
+        rc = seq_sqbox(s, 2);
+        if (rc) return rc;
+        job.sqbox_cur = s->sqbox[2] + (size_t)fd * p.stride;
+        job.sqbox_stride = p.stride;
+    }
     return launch_bbme(s->ctx, job);
 }
 
@@ -531,6 +565,7 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
             if (rc) return rc;
         }
         s->pyramids_valid = true;
+        s->sqbox_valid[0] = s->sqbox_valid[1] = false;
     }
     if (s->gme_alloc_pairs != (size_t)pairs || s->gme_bs != bbme_bs) {
         rc = alloc_fit(s->fit[0], pairs, s->level[0].H / 2, s->level[0].W / 2, false);
@@ -562,6 +597,12 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
         job.pnorm = GME_NORM_MSE;
         job.mf = s->fit[l].gt; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
         if (s->fit[l].h == 0 || s->fit[l].w == 0) continue;
+        if (bbme_wants_sqbox(job.bs, job.sw, job.procedure, job.pnorm)) {      // BASELINE config 4
+            rc = seq_sqbox(s, l);
+            if (rc) return rc;
+            job.sqbox_cur = s->sqbox[l] + (size_t)fd * p.stride;
+            job.sqbox_stride = p.stride;
+        }
         rc = launch_bbme(ctx, job);
         if (rc) return rc;
     }

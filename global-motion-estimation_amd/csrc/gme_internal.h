@@ -80,8 +80,11 @@ struct gme_seq {
     int32_t* mv = nullptr;        // [P][h][w][2]
     size_t mv_bytes = 0;
     int mv_h = 0, mv_w = 0, mv_pairs = 0;
-    uint32_t* sqbox = nullptr;    // per-frame table of 16x16 box sums of squares (MSE fast path)
-    size_t sqbox_bytes = 0;
+    uint32_t* sqbox[3] = { nullptr, nullptr, nullptr };   // per level: 16x16 box sums of squares per frame (MSE fast path)
+    size_t sqbox_bytes[3] = { 0, 0, 0 };
+    bool sqbox_valid[3] = { false, false, false };
+    uint32_t* sqtmp = nullptr;    // row-pass scratch, sized for the largest level in use
+    size_t sqtmp_bytes = 0;
     // GME state
     int gme_fd = 0, gme_bs = 0, gme_pairs = 0;
     FitLevelBuf fit[3];           // fit[0].gt = dense field
@@ -114,6 +117,10 @@ struct BbmeJob {
     int64_t sqbox_stride;         // elements between consecutive planes
 };
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
+int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
+                   uint32_t* tmp, uint32_t* out, long long stride);
+// true when launch_bbme would take the fast exhaustive-MSE kernel if given a box table
+bool bbme_wants_sqbox(int bs, int sw, int procedure, int pnorm);
 int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
 
 // ---- gme_kernels.hip --------------------------------------------------------

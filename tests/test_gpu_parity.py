@@ -352,3 +352,51 @@ def test_full_size_1080p(golden, mods):
         want = np.concatenate([g["gme_l%d_F" % lvl].reshape(9), g["gme_l%d_Sx" % lvl], g["gme_l%d_Sy" % lvl]])
         assert sums.tobytes() == want.tobytes()
     np.testing.assert_allclose(motion.global_motion_estimation(p, c), g["gme_params"], rtol=1e-10, atol=1e-12)
+
+
+def _oracle_gme(prev, cur, procedure, sw, bs=16, frac=0.3):
+    """motion.global_motion_estimation through the C oracle with a selectable BBME at levels 1-2
+    (BASELINE config 4 fits the affine model to an exhaustive-search field)."""
+    co, o = c_oracle(), np_oracle()
+    pp = [co.pyrdown(co.pyrdown(prev)), co.pyrdown(prev), prev]
+    cp = [co.pyrdown(co.pyrdown(cur)), co.pyrdown(cur), cur]
+    params = co.first_parameters(co.bbme(pp[0], cp[0], 2, 2, 3, 1))
+    stages = []
+    for lvl in (1, 2):
+        params = o.project_parameters(params)
+        gt = co.bbme(pp[lvl], cp[lvl], bs, sw, procedure, 1)
+        st = co.fit_level(gt, params, frac, pp[lvl].shape)
+        st["gt"] = gt
+        stages.append(st)
+        params = o.solve_parameters(st["F"], st["Sx"], st["Sy"])
+    return params, stages
+
+
+@pytest.mark.parametrize("procedure,sw", [(0, 8), (0, 16), (1, 7), (2, 6)])
+def test_gme_with_other_searches(mods, procedure, sw):
+    """gme_seq_gme_begin's procedure/search_window arguments (exhaustive MSE = BASELINE config 4)."""
+    native, _, motion, _ = mods
+    import synth
+    frames = synth.sequence(31, 2, 3, 144, 208)
+    seq = native.Sequence.from_frames(native.default_context(), frames)
+    got = motion.estimate_sequence(seq, 1, procedure, sw)
+    for p in range(2):
+        want, stages = _oracle_gme(frames[p], frames[p + 1], procedure, sw)
+        for lvl in (1, 2):
+            st = seq.gme_read_stage(lvl, p)
+            assert np.array_equal(st["gt"], stages[lvl - 1]["gt"]), (p, lvl)
+        assert np.array_equal(seq.gme_read_stage(2, p)["mask"], stages[1]["mask"])
+        np.testing.assert_allclose(got[p], want, rtol=1e-9, atol=1e-11)
+    seq.close()
+
+
+def test_generic_kernels_still_match(mods, monkeypatch):
+    """GME_FORCE_GENERIC routes bs=16 / bs=2 work through k_walk<G> and k_exh_generic (the kernels
+    other block sizes use); they must agree with the specialised ones."""
+    native, bbme, _, _ = mods
+    import synth
+    p, c = synth.frame(9, 0, 80, 112), synth.frame(9, 1, 80, 112)
+    fast = {(sp, pn, bs): bbme.get_motion_field(p, c, bs, 8, sp, pn) for sp in range(4) for pn in range(2) for bs in (16, 2)}
+    monkeypatch.setenv("GME_FORCE_GENERIC", "1")
+    for (sp, pn, bs), want in fast.items():
+        assert np.array_equal(bbme.get_motion_field(p, c, bs, 8, sp, pn), want), (sp, pn, bs)
