@@ -81,3 +81,68 @@ diamond_search = _search(DIAMOND)            # bbme.py:436-534
 diamond_search.__doc__ = "bbme.py:436-534 (search_window is ignored there too)."
 
 searching_procedures = [exhaustive_search, threestep_search, twodlog_search, diamond_search]
+
+
+def rescale_motion_field(motion_field, scale=2):
+    """bbme.py:537-546: nearest-neighbour upsampling by `scale`, stored as int32 (float input is
+    truncated toward zero on the store), then multiplied by 2 -- always 2, whatever `scale` is."""
+    mf = np.zeros((motion_field.shape[0] * scale, motion_field.shape[1] * scale, 2), dtype=np.int32)
+    mf[...] = np.repeat(np.repeat(np.asarray(motion_field)[:, :, :2], scale, axis=0), scale, axis=1)
+    return mf * 2
+
+
+def hierarchical_wrapper(previous, current, block_size=10, search_window=4, searching_procedure=3):
+    """bbme.py:549-605: coarse-to-fine BBME over the 3-level pyramid.  The coarsest level uses
+    `searching_procedure`, the finer ones always diamond; each level's field is averaged with the
+    rescaled field of the level above, so the result is float64."""
+    from utils import get_pyramids
+    previous_pyr = get_pyramids(previous, levels=3)
+    current_pyr = get_pyramids(current, levels=3)
+    motion_field = get_motion_field(previous_pyr[0], current_pyr[0], block_size=block_size,
+                                    searching_procedure=searching_procedure, search_window=search_window)
+    for level in range(1, len(previous_pyr)):
+        motion_field = rescale_motion_field(motion_field, scale=2)
+        new_mf = get_motion_field(previous_pyr[level], current_pyr[level], block_size=block_size,
+                                  searching_procedure=3, search_window=search_window)
+        if motion_field.shape != new_mf.shape:          # bbme.py:596-602: pad ONE axis by one line
+            if motion_field.shape[0] != new_mf.shape[0]:
+                motion_field = np.vstack([motion_field, np.zeros((1, motion_field.shape[1], 2), dtype=np.int32)])
+            else:
+                motion_field = np.hstack([motion_field, np.zeros((motion_field.shape[0], 1, 2), dtype=np.int32)])
+        motion_field = (motion_field + new_mf) / 2
+    return motion_field
+
+
+def main(args):
+    """bbme.py:617-649: field + hierarchical field between frames fi-3 and fi, drawn and saved.
+    As upstream, ``-pn`` is parsed but not forwarded (the norm stays MSE)."""
+    import os
+    from utils import draw_motion_field, get_video_frames, write_image
+    frames = get_video_frames(args.path)
+    previous, current = frames[args.fi - 3], frames[args.fi]
+    motion_field = get_motion_field(previous, current, block_size=args.block_size,
+                                    searching_procedure=args.searching_procedure, search_window=args.search_window)
+    motion_field_hierarchical = hierarchical_wrapper(previous, current, block_size=args.block_size,
+                                                     search_window=args.search_window,
+                                                     searching_procedure=args.searching_procedure)
+    out_dir = os.path.join("resources", "images")
+    os.makedirs(out_dir, exist_ok=True)
+    write_image(os.path.join(out_dir, f"{args.searching_procedure}-res.png"), draw_motion_field(current, motion_field))
+    write_image(os.path.join(out_dir, f"{args.searching_procedure}h-res.png"),
+                draw_motion_field(previous, motion_field_hierarchical))
+    return motion_field, motion_field_hierarchical
+
+
+if __name__ == "__main__":
+    import argparse
+    parser = argparse.ArgumentParser(description="Computes motion field between two frames using block matching algorithms")
+    parser.add_argument("-p", "--video-path", dest="path", type=str, required=True, help="path of the video to analyze")
+    parser.add_argument("-fi", "--frame-index", dest="fi", type=int, required=True,
+                        help="index of the current frame to analyze in the video")
+    parser.add_argument("-pn", "--p-norm", dest="pnorm", type=int, default=0, help="0: 1-norm (mae), 1: 2-norm (mse)")
+    parser.add_argument("-bs", "--block-size", dest="block_size", type=int, default=12, help="size of the block")
+    parser.add_argument("-sw", "--search-window", dest="search_window", type=int, default=8,
+                        help="size of the search window")
+    parser.add_argument("-sp", "--searching-procedure", dest="searching_procedure", type=int, default=1,
+                        help="0: Exhaustive search, 1: Three Step search, 2: 2D Log search, 3: Diamond search")
+    main(parser.parse_args())

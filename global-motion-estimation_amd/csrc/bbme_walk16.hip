@@ -38,6 +38,16 @@ __device__ __forceinline__ int clamp_ref(int v, int hi)   // min(max(v, 0), hi),
     return t < hi ? t : hi;
 }
 
+// sum over the 8 lanes of a group (lanes 8g .. 8g+7) with DPP moves: xor 1, xor 2 inside
+// the quad, then the half-row mirror brings in the other quad
+__device__ __forceinline__ unsigned group8_sum(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    return v;
+}
+
 // cost of up to 8 candidates (one per 8-lane group); positions are wave-uniform arrays.
 // Returns the group's candidate cost in every lane of the group (INF32 if !valid).
 template <int PNORM>
@@ -69,15 +79,82 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
             part = aa + bb - 2u * ab;          // sum over this lane's 32 pixels of (a-b)^2
         }
     }
-    part += __shfl_xor((int)part, 1, 64);
-    part += __shfl_xor((int)part, 2, 64);
-    part += __shfl_xor((int)part, 4, 64);
+    part = group8_sum(part);
+    return valid ? part : INF32;
+}
+
+// Search-window cache: WIN_ROWS x WIN_DW dwords of `cur` per wave in LDS (row pitch WIN_PITCH is
+// odd, so the 8 lanes of a group -- 2 rows apart -- hit 8 different banks).  A candidate block
+// (rr, cc) can be served from it when 0 <= rr - wr0 <= WIN_ROWS - 16 and 0 <= cc - wc0 <= WIN_SPAN.
+constexpr int WIN_ROWS = 40, WIN_DW = 12, WIN_PITCH = 13, WIN_SPAN = 4 * (WIN_DW - 5) + 3;
+
+__device__ __forceinline__ void stage_walk_window(uint32_t* lds, const uint8_t* cur, int pitch, int H, int wr0,
+                                                  int wc0, int lane)
+{
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int seg = lane + 64 * it;                 // 3 sixteen-byte segments per row
+        if (seg < WIN_ROWS * 3) {
+            const int row = seg / 3, s4 = seg - row * 3;
+            const int gy = wr0 + row, gx = wc0 + 16 * s4;
+            uint32_t v[4] = { 0, 0, 0, 0 };
+            if (gy >= 0 && gy < H) {
+                const uint8_t* p = cur + (long long)gy * pitch + gx;
+                if (gx >= 0 && gx + 16 <= pitch) {
+                    const u32x4_a4 t = *(const u32x4_a4*)p;
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gx + 4 * q >= 0 && gx + 4 * q < pitch) v[q] = *(const uint32_t*)(p + 4 * q);
+                }
+            }
+            uint32_t* o = lds + row * WIN_PITCH + 4 * s4;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                    // LDS ops of one wave complete in order
+}
+
+template <int PNORM>
+__device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int wr0,
+                                                   int wc0, int rr, int cc, bool valid, int lrow)
+{
+    unsigned part = 0;
+    if (valid) {
+        const int bc = cc - wc0;
+        const uint32_t sh = (uint32_t)bc & 3u;
+        const uint32_t* p = lds + (rr - wr0 + lrow) * WIN_PITCH + (bc >> 2);
+        uint32_t l0[5], l1[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[WIN_PITCH + j]; }
+        uint32_t b[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = __builtin_amdgcn_alignbyte(l0[j + 1], l0[j], sh);
+            b[4 + j] = __builtin_amdgcn_alignbyte(l1[j + 1], l1[j], sh);
+        }
+        if (PNORM == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part = __builtin_amdgcn_sad_u8(a[j], b[j], part);
+        } else {
+            unsigned bb = 0, ab = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
+                ab = __builtin_amdgcn_udot4(a[j], b[j], ab, false);
+            }
+            part = aa + bb - 2u * ab;
+        }
+    }
+    part = group8_sum(part);
     return valid ? part : INF32;
 }
 
 template <int PNORM>
 __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
 {
+    __shared__ uint32_t win_all[4][WIN_ROWS * WIN_PITCH];
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long gid = (long long)blockIdx.x * 4 + wave_in_wg;
     const int nblk = d.nbr * d.nbc;
@@ -101,12 +178,33 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         for (int j = 0; j < 8; ++j) aa = __builtin_amdgcn_udot4(a[j], a[j], aa, false);
     }
 
-    // evaluate n <= 8 candidates (cr[k], cc[k], ok[k]) -> cost[k], all wave-uniform
+    // evaluate n <= 8 candidates (cr[k], cc[k], ok[k]) -> cost[k], all wave-uniform.
+    // Candidates are served from the LDS window; when some fall outside it the window is moved
+    // (centred on their bounding box) and, if the pattern is wider than the window (first steps
+    // of three-step / 2-D log), this round reads global memory directly.
+    uint32_t* win = win_all[wave_in_wg];
+    int wr0 = 0, wc0 = 0;
+    bool have_win = false;
 #define EVAL8(n, CR, CC, OK, COST)                                                                   \
     do {                                                                                             \
+        int rmin_ = 1 << 30, rmax_ = -(1 << 30), cmin_ = 1 << 30, cmax_ = -(1 << 30);                \
+        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (OK[k_]) {                             \
+            rmin_ = min(rmin_, CR[k_]); rmax_ = max(rmax_, CR[k_]);                                  \
+            cmin_ = min(cmin_, CC[k_]); cmax_ = max(cmax_, CC[k_]); }                                \
+        bool lds_ok_ = rmax_ >= rmin_;                                                               \
+        if (lds_ok_ && !(have_win && rmin_ >= wr0 && rmax_ <= wr0 + WIN_ROWS - 16 && cmin_ >= wc0 && \
+                         cmax_ <= wc0 + WIN_SPAN)) {                                                 \
+            if (rmax_ - rmin_ <= WIN_ROWS - 16 && cmax_ - cmin_ <= WIN_SPAN - 3) {                   \
+                wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                 \
+                wc0 = (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3;                           \
+                stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                               \
+                have_win = true;                                                                     \
+            } else lds_ok_ = false;                                                                  \
+        }                                                                                            \
         int rr_ = 0, cc_ = 0; bool ok_ = false;                                                      \
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (grp == k_) { rr_ = CR[k_]; cc_ = CC[k_]; ok_ = OK[k_]; } \
-        const unsigned c_ = group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);               \
+        const unsigned c_ = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, wr0, wc0, rr_, cc_, ok_, lrow)  \
+                                    : group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);     \
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
     } while (0)
 

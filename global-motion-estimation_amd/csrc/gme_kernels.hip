@@ -220,10 +220,26 @@ __global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h,
         const int a = c < 6 ? fa[c] : (c - 6) % 3;
         const int b = c < 6 ? fb[c] : (c < 9 ? 3 : 4);          // 3, 4: the two motion-vector channels
         double acc = 0.0;
-        for (int e = 0; e < m; ++e) {
+        // terms of 8 entries are formed independently (loads, converts, two multiplies pipeline),
+        // then added to the chain one by one in list order -- only the adds are serial
+        int e = 0;
+        for (; e + 8 <= m; e += 8) {
+            double term[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int4 v = list[e + u];
+                const int va = a == 0 ? 1 : (a == 1 ? v.x : v.y);
+                const int vb = b == 0 ? 1 : (b == 1 ? v.x : (b == 2 ? v.y : (b == 3 ? v.z : v.w)));
+                term[u] = __dmul_rn(__dmul_rn((double)va, (double)vb), wgt);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, term[u]);
+        }
+        for (; e < m; ++e) {
             const int4 v = list[e];
-            const int vi[5] = { 1, v.x, v.y, v.z, v.w };         // literal 4 already applied (motion.py:254-255)
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)vi[a], (double)vi[b]), wgt));
+            const int va = a == 0 ? 1 : (a == 1 ? v.x : v.y);
+            const int vb = b == 0 ? 1 : (b == 1 ? v.x : (b == 2 ? v.y : (b == 3 ? v.z : v.w)));
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)va, (double)vb), wgt));
         }
         double* s = sums_all + (long long)pair * 15;
         if (c < 6) { s[fa[c] * 3 + fb[c]] = acc; s[fb[c] * 3 + fa[c]] = acc; }

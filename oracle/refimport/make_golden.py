@@ -23,6 +23,8 @@ What the files hold:
                 first-parameter means, degenerate fits, 2D-log sw in {1,2,3}, PSNR
   g7_sequence   6-frame 128x192 synthetic sequence, frame distance 1 and 2: params,
                 compensated-frame hashes, PSNR per pair (results.py:41-112 flow)
+  g8_next       SURVEY §8(f): hierarchical_wrapper, rescale_motion_field, psnr_records strings,
+                some_data output
 """
 import hashlib
 import os
@@ -410,8 +412,58 @@ def g7(pool):
     np.savez_compressed(os.path.join(OUT, "g7_sequence.npz"), **data)
 
 
+def _g8_job(args):
+    tag, sp = args
+    if tag == "small":
+        p, c = synth.frame(77, 3, 128, 192), synth.frame(77, 4, 128, 192)
+    elif tag == "odd":                     # pyramid shapes that need the one-line padding of bbme.py:596-602
+        p, c = synth.frame(79, 0, 150, 210), synth.frame(79, 1, 150, 210)
+    else:
+        p, c = load_png("pan240-prev-frame.png"), load_png("pan240-curr-frame.png")
+    bs, sw = (10, 4) if tag != "odd" else (6, 3)
+    try:
+        return tag, sp, bbme.hierarchical_wrapper(p, c, block_size=bs, search_window=sw, searching_procedure=sp), ""
+    except Exception as e:
+        return tag, sp, None, type(e).__name__
+
+
+def g8(pool):
+    """SURVEY §8(f) "next" rows: hierarchical BBME, rescale, PSNR record strings, some_data."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    rng = np.random.default_rng(808)
+    data = {}
+    for tag, sp, mf, err in pool.map(_g8_job, [(t, sp) for t in ("small", "odd", "pan240") for sp in (3, 1, 0)]):
+        data["hier_%s_sp%d_err" % (tag, sp)] = err
+        if mf is not None:
+            data["hier_%s_sp%d" % (tag, sp)] = mf
+    a = rng.integers(-9, 10, (5, 7, 2)).astype(np.int32)
+    b = rng.normal(0, 3, (4, 6, 2))
+    data["resc_in_int"], data["resc_out_int"] = a, bbme.rescale_motion_field(a)
+    data["resc_in_float"], data["resc_out_float"] = b, bbme.rescale_motion_field(b, scale=2)
+    data["resc_out_int3"] = bbme.rescale_motion_field(a, scale=3)
+    # psnr_records.json strings exactly as results.py:109-110 makes them
+    g7 = np.load(os.path.join(OUT, "g7_sequence.npz"))
+    frames = synth.sequence(2000, 0, 6, 128, 192)
+    rec = {}
+    for i in range(1, 6):
+        rec[str(i)] = str(utils.PSNR(frames[i], g7["fd1_i%d_comp" % i]))
+    rec["6"] = rec["2"]                      # a duplicate value exercises some_data's index() quirk
+    data["psnr_records_json"] = json.dumps(rec)
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(rec, f)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        utils.some_data(f.name)
+    os.unlink(f.name)
+    data["some_data_stdout"] = out.getvalue()
+    np.savez_compressed(os.path.join(OUT, "g8_next.npz"), **data)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     os.makedirs(OUT, exist_ok=True)
     with Pool(8) as pool:
         for name in which:

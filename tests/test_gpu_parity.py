@@ -400,3 +400,44 @@ def test_generic_kernels_still_match(mods, monkeypatch):
     monkeypatch.setenv("GME_FORCE_GENERIC", "1")
     for (sp, pn, bs), want in fast.items():
         assert np.array_equal(bbme.get_motion_field(p, c, bs, 8, sp, pn), want), (sp, pn, bs)
+
+
+def test_hierarchical_wrapper_and_results_flow(golden, mods, tmp_path, capsys):
+    """bbme.hierarchical_wrapper, the results.py driver and its records."""
+    import json
+    _, bbme, _, utils = mods
+    import results
+    import synth
+    from test_oracle import _gme_inputs
+    g = golden("g8_next")
+    for tag in ("small", "odd", "pan240"):
+        if tag == "odd":
+            p, c = synth.frame(79, 0, 150, 210), synth.frame(79, 1, 150, 210)
+        else:
+            p, c = _gme_inputs(golden, tag)
+        bs, sw = (10, 4) if tag != "odd" else (6, 3)
+        for sp in (3, 1, 0):
+            err = str(g["hier_%s_sp%d_err" % (tag, sp)])
+            if err:
+                with pytest.raises(ValueError):
+                    bbme.hierarchical_wrapper(p, c, block_size=bs, search_window=sw, searching_procedure=sp)
+            else:
+                got = bbme.hierarchical_wrapper(p, c, block_size=bs, search_window=sw, searching_procedure=sp)
+                assert got.dtype == np.float64 and np.array_equal(got, g["hier_%s_sp%d" % (tag, sp)]), (tag, sp)
+    # results.py flow: the JSON strings of psnr_records.json and the files it writes
+    frames = list(synth.sequence(2000, 0, 6, 128, 192))
+    want = json.loads(str(g["psnr_records_json"]))
+    save = str(tmp_path) + "/"
+    for sub in ("frames", "compensated", "curr_prev_diff", "model_motion_field", "curr_comp_diff"):
+        (tmp_path / sub).mkdir()
+    rec = results.process_frames(frames, 1, save)
+    assert rec == {k: want[k] for k in "12345"}
+    assert json.load(open(save + "psnr_records.json")) == rec
+    from PIL import Image
+    g7 = golden("g7_sequence")
+    assert np.array_equal(np.array(Image.open(save + "compensated/-2.png")), g7["fd1_i3_comp"])   # idx-5 naming
+    assert np.array_equal(np.array(Image.open(save + "frames/0.png")), frames[4])
+    diff = np.abs(frames[2].astype(int) - g7["fd1_i2_comp"].astype(int)).astype(np.uint8)
+    assert np.array_equal(np.array(Image.open(save + "curr_comp_diff/2.png")), diff)
+    assert Image.open(save + "model_motion_field/5.png").size == (192, 128)
+    assert results.process_frames(frames[:1], 1) == {}

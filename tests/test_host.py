@@ -162,3 +162,46 @@ def test_synth_generator_self_checks():
     assert list(synth.canvas(1234)[0, :8]) == [140, 141, 145, 142, 143, 135, 134, 141]
     assert sha(synth.frame(1234, 0, 480, 720)) == "9736c2ac7184b594c41cb75edac231feac5775691bca78fc0af2cb8674ae7308"
     assert sha(synth.frame(1234, 1, 480, 720)) == "9652a5b6f736753131bdcc1961978ceb4238d311bb56ddba6e66d15ddffa7217"
+
+
+def test_rescale_motion_field_and_some_data(golden, tmp_path, capsys):
+    """bbme.rescale_motion_field (bbme.py:537-546) and utils.some_data (utils.py:138-164)."""
+    import bbme
+    import utils
+    g = golden("g8_next")
+    for tag in ("int", "float"):
+        got = bbme.rescale_motion_field(g["resc_in_" + tag])
+        assert got.dtype == np.int32 and np.array_equal(got, g["resc_out_" + tag]), tag
+    assert np.array_equal(bbme.rescale_motion_field(g["resc_in_int"], scale=3), g["resc_out_int3"])
+    path = tmp_path / "psnr_records.json"
+    path.write_text(str(g["psnr_records_json"]))
+    utils.some_data(str(path))
+    assert capsys.readouterr().out == str(g["some_data_stdout"])
+
+
+def test_frame_loaders_without_cv2(tmp_path):
+    """utils.get_video_frames on an image directory, a .npy stack and a .y4m file."""
+    import synth
+    import utils
+    from PIL import Image
+    frames = synth.sequence(3, 0, 4, 48, 64)
+    d = tmp_path / "clip"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(d / ("f%d.png" % (i + 9)))          # 9, 10, 11, 12: numeric, not lexical, order
+    got = utils.get_video_frames(str(d))
+    assert len(got) == 4 and all(np.array_equal(a, b) for a, b in zip(got, frames))
+    np.save(tmp_path / "clip.npy", frames)
+    assert np.array_equal(np.array(utils.get_video_frames(str(tmp_path / "clip.npy"))), frames)
+    with open(tmp_path / "clip.y4m", "wb") as f:
+        f.write(b"YUV4MPEG2 W64 H48 F30:1 Ip A1:1 C420jpeg\n")
+        for fr in frames:
+            f.write(b"FRAME\n" + fr.tobytes() + bytes(64 * 48 // 2))
+    got = utils.get_video_frames(str(tmp_path / "clip.y4m"))
+    assert len(got) == 4 and all(np.array_equal(a, b) for a, b in zip(got, frames))
+    # needle diagram: BGR image of the frame's size; vectors drawn in red
+    mf = np.zeros((3, 4, 2), np.int32)
+    mf[1, 2] = (5, -3)
+    img = utils.draw_motion_field(frames[0], mf)
+    assert img.shape == (48, 64, 3) and img.dtype == np.uint8
+    assert (img[:, :, 2] == 255).any() and utils.write_image(str(tmp_path / "o.png"), img)
