@@ -23,8 +23,8 @@ class GmeError(RuntimeError):
 
 
 class GmeInexactError(ArithmeticError):
-    """The requested block size / norm leaves float32's exact-integer range, where the
-    reference's own result depends on NumPy's summation order (bbme.py:61-64)."""
+    """Reserved (GME_ERR_INEXACT).  Outside float32's exact-integer range (MSE with bs > 16) the
+    kernels reproduce NumPy's float32 pairwise summation order, so nothing raises this today."""
 
 
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)

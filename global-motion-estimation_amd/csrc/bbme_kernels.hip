@@ -26,7 +26,61 @@ struct Dev {
     int nbr, nbc;
     int32_t* mf;
     int* status;
+    int f32;                      // block distances in NumPy's float32 pairwise order (see block_cost_f32)
 };
+
+// ---------------------------------------------------------------------------
+// Block distance exactly as the reference computes it when the sum leaves float32's
+// exact-integer range (MSE with bs > 16, MAE with bs > 256): compute_dfd (bbme.py:41-64,79,94)
+// hands a contiguous float32 bs x bs array to np.sum, which reduces the flat n = bs*bs
+// elements with NumPy's pairwise summation -- 8 strided accumulators over blocks of <= 128
+// elements, halves split at multiples of 8 (numpy/core/src/umath/loops_utils.h.src).  The
+// emulation below reproduces that order bit for bit (checked against np.sum under NumPy
+// 1.26.4 and 2.2.6 in tests/test_host.py).  Non-negative floats order like their bit patterns.
+// ---------------------------------------------------------------------------
+struct BlockPair {
+    const uint8_t* a;
+    const uint8_t* c;
+    int pitch, bs, pnorm;
+    __device__ __forceinline__ float operator()(int idx) const
+    {
+        const int y = idx / bs, x = idx - y * bs;
+        const float df = (float)a[y * pitch + x] - (float)c[y * pitch + x];
+        return pnorm ? __fmul_rn(df, df) : fabsf(df);
+    }
+};
+
+__device__ float pairwise_f32(const BlockPair& e, int start, int n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, e(start + i));
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = e(start + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], e(start + i + j));
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, e(start + i));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(pairwise_f32(e, start, n2), pairwise_f32(e, start + n2, n - n2));
+}
+
+__device__ __forceinline__ unsigned long long block_cost_f32(const uint8_t* a, const uint8_t* c, int pitch, int bs,
+                                                             int pnorm)
+{
+    const BlockPair e{ a, c, pitch, bs, pnorm };
+    return (unsigned long long)__float_as_uint(pairwise_f32(e, 0, bs * bs));
+}
 
 __device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b)
 {
@@ -61,7 +115,8 @@ __global__ void __launch_bounds__(256) k_exh_generic(Dev d)
         if (top < 0 || left < 0 || top + d.bs > d.H || left + d.bs > d.W) continue;
         const uint8_t* cand = cur + (long long)top * d.pitch + left;
         unsigned long long cost = 0;
-        for (int y = 0; y < d.bs; ++y) {
+        if (d.f32) cost = block_cost_f32(prev, cand, d.pitch, d.bs, d.pnorm);
+        else for (int y = 0; y < d.bs; ++y) {
             const uint8_t* a = prev + (long long)y * d.pitch;
             const uint8_t* c = cand + (long long)y * d.pitch;
             unsigned row = 0;
@@ -94,8 +149,9 @@ __global__ void __launch_bounds__(256) k_exh_generic(Dev d)
 // ---------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ unsigned long long group_cost(const uint8_t* anchor, const uint8_t* cand,
-                                                         int pitch, int bs, int pnorm, int lig)
+                                                         int pitch, int bs, int pnorm, int lig, int f32)
 {
+    if (G == 1 && f32) return block_cost_f32(anchor, cand, pitch, bs, pnorm);
     unsigned long long acc = 0;
     const int n = bs * bs;
     int y = lig / bs, x = lig - y * bs;
@@ -139,7 +195,7 @@ __global__ void __launch_bounds__(256) k_walk(Dev d)
     bool overrun = false;
     int out0 = 0, out1 = 0;
 
-#define COST_AT(rr, cc) group_cost<G>(anchor, cur + (long long)(rr) * pitch + (cc), pitch, bs, pnorm, lig)
+#define COST_AT(rr, cc) group_cost<G>(anchor, cur + (long long)(rr) * pitch + (cc), pitch, bs, pnorm, lig, d.f32)
 #define INSIDE(rr, cc) ((rr) >= 0 && (cc) >= 0 && (rr) + bs <= H && (cc) + bs <= W)
 
     if (d.procedure == GME_SEARCH_DIAMOND) {           // bbme.py:436-534
@@ -247,11 +303,7 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
     GME_REQUIRE(pnorm == 0 || pnorm == 1, GME_ERR_ARG, "pnorm_distance %d out of range (bbme.py:60)", pnorm);
     GME_REQUIRE(bs >= 1 && H >= 1 && W >= 1, GME_ERR_ARG, "bad geometry H=%d W=%d bs=%d", H, W, bs);
     GME_REQUIRE(bs <= 4096, GME_ERR_ARG, "block_size %d too large", bs);
-    const double worst = (double)bs * bs * (pnorm ? 65025.0 : 255.0);
-    GME_REQUIRE(worst < 16777216.0, GME_ERR_INEXACT,
-                "block_size %d with %s leaves float32's exact-integer range (bbme.py:61-64): "
-                "the reference's own result depends on NumPy's summation order there",
-                bs, pnorm ? "MSE" : "MAE");
+    GME_REQUIRE((long long)bs * bs < (1ll << 30), GME_ERR_ARG, "block_size %d too large", bs);
     if (procedure == GME_SEARCH_EXHAUSTIVE) {
         GME_REQUIRE(sw >= 0 && 2 * sw + bs < 4096, GME_ERR_ARG, "search_window %d out of range", sw);
     }
@@ -265,11 +317,18 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
 int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 
+// the reference's float32 sums stop being exact integers at 2^24 (bbme.py:61-64)
+static bool needs_f32_order(int bs, int pnorm)
+{
+    return (double)bs * bs * (pnorm ? 65025.0 : 255.0) >= 16777216.0;
+}
+
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
 {
     int rc = bbme_check_args(job.H, job.W, job.bs, job.sw, job.procedure, job.pnorm);
     if (rc != GME_OK) return rc;
     Dev d;
+    d.f32 = needs_f32_order(job.bs, job.pnorm) ? 1 : 0;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch;
     d.bs = job.bs; d.sw = job.sw; d.pnorm = job.pnorm; d.procedure = job.procedure;
@@ -293,7 +352,8 @@ int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
         hipLaunchKernelGGL(k_exh_generic, dim3((unsigned)(nblk * job.pairs)), dim3(256), 0, ctx->stream, d);
     } else {
         const int px = job.bs * job.bs;
-        const int G = px <= 4 ? 1 : px <= 16 ? 4 : px <= 64 ? 16 : 64;
+        // float32-order costs are sequential by definition: one lane per block
+        const int G = d.f32 ? 1 : px <= 4 ? 1 : px <= 16 ? 4 : px <= 64 ? 16 : 64;
         const long long threads = nblk * job.pairs * G;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         switch (G) {

@@ -385,6 +385,28 @@ def g6(pool):
     for sp in (0, 3):
         data["bs32hc_sp%d" % sp] = bbme.get_motion_field(p, c, block_size=32, search_window=6,
                                                          searching_procedure=sp, pnorm_distance=1)
+    # float32 summation order decides the winner: a 32x33 frame has exactly two candidates for its
+    # one 32x32 block (sw=1); search (seeded) for perturbations where the exact integer SSDs and
+    # NumPy's float32 sums disagree about which is smaller / tied (bbme.py:61-64,94,171)
+    frng = np.random.default_rng(3)
+    found = 0
+    while found < 3:
+        c = np.full((32, 33), 255, np.uint8)
+        c[:, 0] = 255 - frng.integers(0, 3, 32)
+        c[:, 32] = 255 - frng.integers(0, 3, 32)
+        k = frng.integers(0, 200)
+        ys, xs = frng.integers(0, 32, k), frng.integers(1, 32, k)
+        c[ys, xs] = 254
+        a, b = c[:, :32].astype(np.int64), c[:, 1:33].astype(np.int64)
+        ia, ib = (a * a).sum(), (b * b).sum()
+        fa, fb = np.sum(c[:, :32].astype(np.float32) ** 2), np.sum(c[:, 1:33].astype(np.float32) ** 2)
+        if (0 if ia <= ib else 1) != (0 if fa <= fb else 1):
+            p0 = np.zeros((32, 33), np.uint8)
+            data["f32tie_cur_%d" % found] = c
+            data["f32tie_mf_%d" % found] = bbme.get_motion_field(p0, c, block_size=32, search_window=1,
+                                                                 searching_procedure=0, pnorm_distance=1)
+            data["f32tie_int_%d" % found] = np.array([ia, ib])
+            found += 1
     np.savez_compressed(os.path.join(OUT, "g6_edges.npz"), **data)
 
 

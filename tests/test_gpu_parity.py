@@ -100,11 +100,22 @@ def test_corner_cases(golden, mods):
     p, c = g1["in_random_50x70_prev"], g1["in_random_50x70_cur"]
     assert np.array_equal(bbme.get_motion_field(p, c, 4, 20, 1, 1), g["tss_wild"])
     assert np.array_equal(bbme.get_motion_field(p, c), g["tss_default"])
-    # MSE with bs = 32 is outside float32's exact range: refused loudly, not approximated
-    with pytest.raises(native.GmeInexactError):
-        bbme.get_motion_field(g["bs32_prev"], g["bs32_cur"], 32, 4, 0, 1)
-    # ... while MAE at bs = 32 is exact
+    # MSE with bs = 32 leaves float32's exact-integer range: the kernels then sum in NumPy's
+    # float32 pairwise order, like the reference (goldens from the real reference)
+    for pre, sw in (("bs32", 4), ("bs32hc", 6)):
+        for sp in (0, 3):
+            got = bbme.get_motion_field(g[pre + "_prev"], g[pre + "_cur"], 32, sw, sp, 1)
+            assert np.array_equal(got, g["%s_sp%d" % (pre, sp)]), (pre, sp)
     co = c_oracle()
+    rng = np.random.default_rng(5)
+    hp, hc = (rng.integers(0, 2, (72, 100)) * 255).astype(np.uint8), (rng.integers(0, 2, (72, 100)) * 255).astype(np.uint8)
+    for bs, sw in ((24, 5), (17, 3), (20, 8)):
+        for sp in range(4):
+            assert np.array_equal(bbme.get_motion_field(hp, hc, bs, sw, sp, 1), co.bbme(hp, hc, bs, sw, sp, 1)), (bs, sp)
+    for k in range(3):          # near-ties decided by NumPy's float32 summation order
+        cur = g["f32tie_cur_%d" % k]
+        assert np.array_equal(bbme.get_motion_field(np.zeros_like(cur), cur, 32, 1, 0, 1), g["f32tie_mf_%d" % k]), k
+    # ... while MAE at bs = 32 is exact
     for sp in range(4):
         assert np.array_equal(bbme.get_motion_field(g["bs32_prev"], g["bs32_cur"], 32, 4, sp, 0),
                               co.bbme(g["bs32_prev"], g["bs32_cur"], 32, 4, sp, 0))
@@ -441,3 +452,21 @@ def test_hierarchical_wrapper_and_results_flow(golden, mods, tmp_path, capsys):
     assert np.array_equal(np.array(Image.open(save + "curr_comp_diff/2.png")), diff)
     assert Image.open(save + "model_motion_field/5.png").size == (192, 128)
     assert results.process_frames(frames[:1], 1) == {}
+
+
+def test_gme_block_size_24_follows_float32_order(mods):
+    """The authors' figures use BBME_BLOCK_SIZE 24/32 (presentation/main.tex:426,558): MSE block
+    distances then leave float32's exact range and the NumPy oracle (same float32 sums as the
+    reference) is the yardstick."""
+    _, _, motion, _ = mods
+    import synth
+    o = np_oracle()
+    prev, cur = synth.frame(91, 0, 192, 256), synth.frame(91, 1, 192, 256)
+    old = motion.BBME_BLOCK_SIZE
+    motion.BBME_BLOCK_SIZE = 24
+    try:
+        got = motion.global_motion_estimation(prev, cur)
+    finally:
+        motion.BBME_BLOCK_SIZE = old
+    want = o.global_motion_estimation(prev, cur, block_size=24)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)

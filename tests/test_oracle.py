@@ -269,6 +269,30 @@ def test_numpy_oracle_bs32_float32_costs(golden):
             assert np.array_equal(got, g["%s_sp%d" % (pre, sp)]), (pre, sp)
 
 
+def test_c_oracle_float32_order_costs(golden):
+    """Outside float32's exact-integer range the C oracle emulates NumPy's pairwise float32 sum;
+    it must agree with the real reference (goldens) and with NumPy itself on hard cases."""
+    g = golden("g6_edges")
+    co, o = c_oracle(), np_oracle()
+    for pre, sw in (("bs32", 4), ("bs32hc", 6)):
+        for sp in (0, 3):
+            assert np.array_equal(co.bbme(g[pre + "_prev"], g[pre + "_cur"], 32, sw, sp, 1), g["%s_sp%d" % (pre, sp)]), (pre, sp)
+    rng = np.random.default_rng(11)
+    p = (rng.integers(0, 2, (60, 84)) * 255).astype(np.uint8)
+    c = (rng.integers(0, 2, (60, 84)) * 255).astype(np.uint8)
+    for bs, sw, sp in ((24, 3, 0), (17, 2, 0), (20, 4, 3), (28, 5, 1), (19, 6, 2)):
+        want = o.get_motion_field(p, c, bs, sw, sp, 1)
+        assert np.array_equal(co.bbme(p, c, bs, sw, sp, 1), want), (bs, sw, sp)
+    # crafted near-ties where the summation order decides: the emulation follows the reference,
+    # exact integer costs do not
+    for k in range(3):
+        cur, want = g["f32tie_cur_%d" % k], g["f32tie_mf_%d" % k]
+        prev = np.zeros_like(cur)
+        assert np.array_equal(co.bbme(prev, cur, 32, 1, 0, 1), want), k
+        assert np.array_equal(o.get_motion_field(prev, cur, 32, 1, 0, 1), want), k
+        assert not np.array_equal(co.bbme(prev, cur, 32, 1, 0, 1, allow_inexact=1), want), k
+
+
 def test_numpy_oracle_sequence(golden):
     """results.py:41-112 flow on two pairs of the 6-frame sequence."""
     import synth
