@@ -441,10 +441,17 @@ int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int c
     return GME_OK;
 }
 
-bool bbme_wants_sqbox(int bs, int sw, int procedure, int pnorm)
+int bbme_aux_kind(int bs, int sw, int procedure, int pnorm)
 {
-    if (procedure != GME_SEARCH_EXHAUSTIVE || bs != 16 || pnorm != GME_NORM_MSE) return false;
-    if (sw < 0 || sw % 4 != 0) return false;
+    if (procedure != GME_SEARCH_EXHAUSTIVE || bs != 16 || pnorm != GME_NORM_MSE) return 0;
+    if (sw < 0 || sw % 4 != 0) return 0;
     const int NC = 2 * sw + 16;
-    return (NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC");
+    return ((NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC")) ? 1 : 0;
+}
+
+int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
+                     int pitch, uint32_t* tmp, uint32_t* out, long long stride)
+{
+    if (kind == 1) return launch_sqbox16(ctx, src, src_stride, count, H, W, pitch, tmp, out, stride);
+    return GME_OK;
 }

@@ -315,6 +315,7 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
 }
 
 int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
+int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 
 // the reference's float32 sums stop being exact integers at 2^24 (bbme.py:61-64)
@@ -339,6 +340,8 @@ int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
     GME_REQUIRE(nblk * job.pairs < (1ll << 31) / 64, GME_ERR_ARG, "too many blocks in one launch");
 
     bool handled = false;
+    rc = launch_bbme_sea(ctx, job, &handled);
+    if (rc != GME_OK || handled) return rc;
     rc = launch_bbme_fast(ctx, job, &handled);
     if (rc != GME_OK || handled) return rc;
     if (!getenv("GME_FORCE_GENERIC")) {

@@ -1,0 +1,332 @@
+// Exhaustive MAE search, bs = 16, with exact successive elimination -- same answer as the brute
+// force kernel (bbme_fast.hip: k_exh_qsad16, bbme.py:105-179), a fraction of the SAD work.
+//
+// For a candidate block B and the anchor A, each split into four 8x8 quadrants,
+//     LB(B) = sum_q |sum(A_q) - sum(B_q)|  <=  SAD(A, B)                  (triangle inequality).
+// Once some candidate's true SAD is known (UB), every candidate with LB > UB has SAD > UB >= the
+// minimum: it can neither win nor tie, so skipping it keeps the reference's "first strict
+// minimum in scan order" result bit for bit.
+//
+// Per workgroup (NB adjacent macroblocks, one wave each, as in k_exh_qsad16):
+//   A  stage the search window of `cur` and the anchors in LDS; quadrant sums of each anchor;
+//   A' 8x8 box sums S8 of the staged window, in LDS, two separable passes: the horizontal one is
+//      two v_qsad_pk_u16_u8 against a zero reference (four sliding 8-byte sums per lane-op), the
+//      vertical one packed u16 adds -- no per-frame table, no extra HBM traffic;
+//   B  LB for all NC^2 candidates of the wave's block: four S8 reads, two v_perm_b32 and two
+//      v_sad_u16 per candidate; per lane: min LB of each of its R patches (R rows x 4 columns);
+//   C  UB := SAD of the candidate with the smallest LB and of the zero vector (64 lanes x 1 dword);
+//   D  patches with min LB <= UB go to a workgroup-wide list (LDS atomics);
+//   E  the list is processed 64*NB patches at a time, one patch per lane (R x 16 x 4
+//      v_qsad_pk_u16_u8 against the anchor read from LDS -- lanes of one wave may serve different
+//      blocks), best keys merged with LDS atomicMin; before each chunk entries whose LB exceeds
+//      the tightened UB are dropped;
+//   F  lane 0 of each wave stores its block's vector.
+// On the synthetic and the reference's doc frames 3-6 % of the patches survive.
+#include <stdlib.h>
+
+#include "gme_internal.h"
+
+namespace {
+
+struct SeaDev {
+    const uint8_t* prev;
+    const uint8_t* cur;
+    long long plane_stride;
+    int pairs, H, W, pitch, sw;
+    int nbr, nbc, nb, wg_per_row, wg_per_pair;
+    int pitch_dw, win_rows;
+    int32_t* mf;
+    int xq;                       // S8 quads (4 columns each) per window row
+};
+
+typedef uint64_t u64_a4 __attribute__((aligned(4)));
+typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const int NB = d.nb, T = blockDim.x;
+    const int NC = 2 * d.sw + 16, XQ = d.xq;
+    uint32_t* win = lds;                                   // [win_rows][pitch_dw]
+    uint32_t* anchor = win + d.win_rows * d.pitch_dw;      // [NB][64]
+    uint32_t* best = anchor + NB * 64;                     // [NB]
+    uint32_t* count = best + NB;                           // [1]
+    const int head = d.win_rows * d.pitch_dw + NB * 64 + NB + 1;
+    uint64_t* s8 = (uint64_t*)(lds + ((head + 1) & ~1));   // [NC+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3), 8-byte aligned
+    uint32_t* work = (uint32_t*)(s8 + (16 * R + 8) * XQ);  // [NB*64*R] entries (s8 holds 16R+8 rows)
+    uint32_t* worklb = work + NB * 64 * R;                 // [NB*64*R] their lower bounds
+
+    const int b = blockIdx.x;
+    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    if (pair >= d.pairs) return;                           // whole workgroup
+    const int wg = (b >> 3) % d.wg_per_pair;
+    const int brow = wg / d.wg_per_row;
+    const int bcol0 = (wg - brow * d.wg_per_row) * NB;
+    const int r0 = brow * 16;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bcol = bcol0 + wave;
+    const bool wave_ok = bcol < d.nbc;                     // ragged last workgroup of a block row
+    const int c0 = bcol * 16;
+    const int prow = lane >> 2, q = lane & 3;
+
+    // ---- A: window, anchor, quadrant sums ------------------------------------------------
+    {
+        const int gx0 = bcol0 * 16 - d.sw, gy0 = r0 - d.sw;
+        const int rstep = T / d.pitch_dw;
+        const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
+        const int gx = gx0 + 4 * dw;
+        const bool colok = gx >= 0 && gx < d.pitch;
+        if (row0 < rstep) {
+            const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
+            const long long sstep = (long long)rstep * d.pitch;
+            uint32_t* dst = win + row0 * d.pitch_dw + dw;
+            const int dstep = rstep * d.pitch_dw;
+            for (int row = row0; row < d.win_rows; row += rstep, src += sstep, dst += dstep) {
+                const int gy = gy0 + row;
+                uint32_t v = 0;
+                if (colok && gy >= 0 && gy < d.H) v = *(const uint32_t*)src;
+                *dst = v;
+            }
+        }
+    }
+    uint32_t mine = 0, a01 = 0, a23 = 0;
+    if (wave_ok) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        anchor[wave * 64 + lane] = mine;
+        const uint32_t s = __builtin_amdgcn_sad_u8(mine, 0u, 0u);       // sum of this lane's 4 bytes
+        const int quad = ((lane >> 5) << 1) | ((lane >> 1) & 1);        // (row >= 8) * 2 + (col >= 8)
+        const uint32_t q0 = wave_sum_u32(quad == 0 ? s : 0u), q1 = wave_sum_u32(quad == 1 ? s : 0u);
+        const uint32_t q2 = wave_sum_u32(quad == 2 ? s : 0u), q3 = wave_sum_u32(quad == 3 ? s : 0u);
+        a01 = q0 | (q1 << 16);
+        a23 = q2 | (q3 << 16);
+    }
+    if (threadIdx.x == 0) *count = 0;
+    __syncthreads();
+
+    // ---- A': 8x8 box sums of the window ---------------------------------------------------------
+    // Thread (column quad sq, row chunk ch) walks CH+7 window rows: per row two QSADs against a
+    // zero reference give the four horizontal 8-byte sums r8(row, 4sq .. 4sq+3) (packed u16); the
+    // vertical 8-row sum slides: S8(y) = S8(y-1) + r8(y+7) - r8(y-1), ring of 8 rows in registers.
+    {
+        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+        constexpr int CH = 2 * R + 1;                      // 8 chunks cover NC + 8 = 16R + 8 rows
+        for (int it = threadIdx.x; it < 8 * XQ; it += T) {
+            const int ch = it / XQ, sq = it - ch * XQ;
+            const uint32_t* p = win + (ch * CH) * d.pitch_dw + sq;
+            u16x4 ring[8], sum = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < CH + 7; ++r) {
+                const uint64_t w0 = *(const u64_a4*)(p + r * d.pitch_dw), w1 = *(const u64_a4*)(p + r * d.pitch_dw + 1);
+                const u16x4 h = __builtin_bit_cast(u16x4, __builtin_amdgcn_qsad_pk_u16_u8(
+                                    w1, 0u, __builtin_amdgcn_qsad_pk_u16_u8(w0, 0u, (uint64_t)0)));
+                if (r >= 8) sum -= ring[r & 7];
+                sum += h;
+                ring[r & 7] = h;
+                if (r >= 7) s8[(ch * CH + r - 7) * XQ + sq] = __builtin_bit_cast(uint64_t, sum);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B: lower bounds of the wave's own block --------------------------------------------
+    const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
+    uint32_t patch_lb[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) patch_lb[k] = 0xFFFFFFFFu;
+    uint32_t ub_key = 0xFFFFFFFFu;
+    if (wave_ok) {
+        const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
+        uint32_t lb_key = 0xFFFFFFFFu;                     // (LB << 13 | scan index) of the lane's best bound
+        const bool interior = lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ri = prow * R + i;
+            if (!interior && (ri < lo_r || ri > hi_r)) continue;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int ci0 = q * 4 * R + 4 * k;
+                if (!interior && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
+                const uint64_t* sp = s8 + ri * XQ + wave * 4 + q * R + k;
+                const uint64_t ta = sp[0], tb = sp[2], ba = sp[8 * XQ], bb = sp[8 * XQ + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = ci0 + e;
+                    if (!interior && (ci < lo_c || ci > hi_c)) continue;
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t top = __builtin_amdgcn_perm((uint32_t)(tb >> (32 * (e >> 1))), (uint32_t)(ta >> (32 * (e >> 1))), sel);
+                    const uint32_t bot = __builtin_amdgcn_perm((uint32_t)(bb >> (32 * (e >> 1))), (uint32_t)(ba >> (32 * (e >> 1))), sel);
+                    const uint32_t lb = __builtin_amdgcn_sad_u16(top, a01, __builtin_amdgcn_sad_u16(bot, a23, 0u));
+                    patch_lb[k] = min(patch_lb[k], lb);
+                    lb_key = min(lb_key, (lb << 13) | (uint32_t)(ci * NC + ri));
+                }
+            }
+        }
+        // ---- C: upper bound from two real candidates (cooperative 16x16 SAD, one dword per lane)
+        lb_key = wave_min_u32(lb_key);
+        const int arow = lane >> 2, aj = lane & 3;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int idx = which == 0 ? (int)(lb_key & 0x1FFF) : d.sw * NC + d.sw;     // min-LB candidate, zero vector
+            const int ci = idx / NC, ri = idx - ci * NC;
+            const int byte = wave * 16 + ci + 4 * aj;
+            const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
+            const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
+            const uint32_t sad = wave_sum_u32(__builtin_amdgcn_sad_u8(v, mine, 0u));
+            ub_key = min(ub_key, (sad << 13) | (uint32_t)idx);
+        }
+        if (lane == 0) best[wave] = ub_key;
+        // ---- D: surviving patches -> workgroup list
+        const uint32_t ub = ub_key >> 13;
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (patch_lb[k] <= ub) {
+                const uint32_t slot = atomicAdd(count, 1u);
+                work[slot] = ((uint32_t)wave << 16) | ((uint32_t)lane << 4) | (uint32_t)k;
+                worklb[slot] = patch_lb[k];
+            }
+    }
+    __syncthreads();
+
+    // ---- E: evaluate the listed patches, one per lane ---------------------------------------
+    const int n = (int)*count;
+    for (int base = 0; base < n; base += T) {
+        const int e = base + threadIdx.x;
+        bool active = e < n;
+        uint32_t ent = 0;
+        if (active) {
+            ent = work[e];
+            active = worklb[e] <= (best[ent >> 16] >> 13);             // dropped by a tightened UB
+        }
+        if (active) {
+            const int w2 = ent >> 16, l2 = (ent >> 4) & 63, k2 = ent & 15;
+            const int prow2 = l2 >> 2, q2 = l2 & 3;
+            const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+            const uint32_t* an = anchor + w2 * 64;
+            uint64_t acc[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] = 0;
+#pragma unroll
+            for (int t = 0; t < R + 15; ++t) {
+                uint64_t w[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int a = t - i;
+                    if (a < 0 || a > 15) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+                }
+            }
+            const int c02 = (bcol0 + w2) * 16;
+            const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+            uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int ci = q2 * 4 * R + 4 * k2 + e4;
+                if (ci < lo_c || ci > hi_c) continue;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ri = prow2 * R + i;
+                    if (ri < lo_r || ri > hi_r) continue;
+                    const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                    key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                }
+            }
+            if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+        }
+        __syncthreads();
+    }
+
+    // ---- F: result ------------------------------------------------------------------------------
+    if (wave_ok && lane == 0) {
+        const int idx = (int)(best[wave] & 0x1FFF);
+        const int ci = idx / NC, ri = idx - ci * NC;
+        int32_t* o = d.mf + (((long long)pair * d.nbr + brow) * d.nbc + bcol) * 2;
+        o[0] = ci - d.sw;
+        o[1] = ri - d.sw;
+    }
+}
+
+int pick_pitch_sea(int need, int R)
+{
+    int best_p = need, best_c = 1 << 30;
+    for (int p = need; p < need + 33; ++p) {
+        int conflicts = 0, seen[32];
+        for (int i = 0; i < 32; ++i) seen[i] = 0;
+        for (int prow = 0; prow < 8; ++prow)
+            for (int q = 0; q < 4; ++q) conflicts += seen[((prow * R) * p + q * R) & 31]++;
+        if (conflicts < best_c) { best_c = conflicts; best_p = p; }
+    }
+    return best_p;
+}
+
+}  // namespace
+
+bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm)
+{
+    if (procedure != GME_SEARCH_EXHAUSTIVE || bs != 16 || pnorm != GME_NORM_MAE) return false;
+    if (sw < 0 || sw % 4 != 0) return false;
+    const int NC = 2 * sw + 16;
+    return (NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC") && !getenv("GME_EXH_BRUTE");
+}
+
+int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
+{
+    *handled = false;
+    if (!bbme_sea_applies(job.bs, job.sw, job.procedure, job.pnorm)) return GME_OK;
+    const int NC = 2 * job.sw + 16, R = (NC + 15) / 16;
+    const int nbr = job.H / 16, nbc = job.W / 16;
+    if (nbr == 0 || nbc == 0) return GME_OK;
+    SeaDev d;
+    d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
+    d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
+    d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
+    int nb = 4;
+    for (int cand : {5, 4, 6, 3}) if (nbc % cand == 0) { nb = cand; break; }
+    if (nbc < nb) nb = nbc;
+    d.nb = nb;
+    d.wg_per_row = (nbc + nb - 1) / nb;
+    d.wg_per_pair = d.wg_per_row * nbr;
+    d.win_rows = 16 * R + 15;
+    const int need_dw = (nb - 1) * 4 + 3 * R + (R - 1) + 5;    // base + k + 4 pairs of two dwords
+    d.xq = (4 * R + 4 * (nb - 1) + 2) | 1;                     // S8 columns 0 .. 16R + 16(nb-1) + 7; odd row pitch
+    d.pitch_dw = pick_pitch_sea(need_dw > d.xq + 2 ? need_dw : d.xq + 2, R);
+    const size_t work_dw = 2 * (size_t)nb * 64 * R;
+    const size_t head = (size_t)d.win_rows * d.pitch_dw + (size_t)nb * 64 + nb + 1;
+    const size_t lds = (((head + 1) & ~(size_t)1) + 2 * (size_t)(16 * R + 8) * d.xq + work_dw) * 4;
+    GME_REQUIRE(lds <= 160 * 1024, GME_ERR_ARG, "search window too large for LDS");
+    const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
+    GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
+    const dim3 grid((unsigned)groups), block(64 * nb);
+    switch (R) {
+    case 1: hipLaunchKernelGGL(k_exh_sea16<1>, grid, block, lds, ctx->stream, d); break;
+    case 2: hipLaunchKernelGGL(k_exh_sea16<2>, grid, block, lds, ctx->stream, d); break;
+    case 3: hipLaunchKernelGGL(k_exh_sea16<3>, grid, block, lds, ctx->stream, d); break;
+    case 4: hipLaunchKernelGGL(k_exh_sea16<4>, grid, block, lds, ctx->stream, d); break;
+    default: hipLaunchKernelGGL(k_exh_sea16<5>, grid, block, lds, ctx->stream, d); break;
+    }
+    GME_HIP_TRY(hipGetLastError());
+    *handled = true;
+    return GME_OK;
+}

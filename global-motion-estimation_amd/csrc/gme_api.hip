@@ -219,7 +219,8 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     Carver c;
     const size_t o_prev = c.take(plane + pitch), o_cur = c.take(plane + pitch);
     const size_t o_mf = c.take((size_t)h * w * 2 * sizeof(int32_t));
-    const bool want_sq = bbme_wants_sqbox(block_size, search_window, procedure, pnorm);
+    const int aux = bbme_aux_kind(block_size, search_window, procedure, pnorm);
+    const bool want_sq = aux != 0;
     const size_t o_sq = c.take(want_sq ? plane * 4 : 0), o_sqtmp = c.take(want_sq ? plane * 4 : 0);
     void* base = nullptr;
     rc = ctx_scratch(ctx, c.off, &base);
@@ -234,7 +235,7 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     job.bs = block_size; job.sw = search_window; job.procedure = procedure; job.pnorm = pnorm;
     job.mf = (int32_t*)(b + o_mf); job.sqbox_cur = nullptr; job.sqbox_stride = 0;
     if (want_sq) {
-        rc = launch_sqbox16(ctx, b + o_cur, 0, 1, H, W, pitch, (uint32_t*)(b + o_sqtmp), (uint32_t*)(b + o_sq), 0);
+        rc = launch_aux_table(ctx, aux, b + o_cur, 0, 1, H, W, pitch, (uint32_t*)(b + o_sqtmp), (uint32_t*)(b + o_sq), 0);
         if (rc) return rc;
         job.sqbox_cur = (const uint32_t*)(b + o_sq);
     }
@@ -457,8 +458,8 @@ static int ensure(T** ptr, size_t* have, size_t want_bytes)
     return GME_OK;
 }
 
-// box table of squares for every frame of one pyramid level (exhaustive MSE fast path)
-static int seq_sqbox(gme_seq* s, int level)
+// auxiliary table (bbme_aux_kind) for every frame of one pyramid level
+static int seq_sqbox(gme_seq* s, int level, int kind)
 {
     const Plane& p = s->level[level];
     const size_t bytes = (size_t)p.stride * p.count * sizeof(uint32_t);
@@ -466,10 +467,11 @@ static int seq_sqbox(gme_seq* s, int level)
     if (rc) return rc;
     rc = ensure(&s->sqtmp, &s->sqtmp_bytes, bytes);
     if (rc) return rc;
-    if (!s->sqbox_valid[level]) {
-        rc = launch_sqbox16(s->ctx, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqtmp, s->sqbox[level], p.stride);
+    if (!s->sqbox_valid[level] || s->sqbox_kind[level] != kind) {
+        rc = launch_aux_table(s->ctx, kind, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqtmp, s->sqbox[level], p.stride);
         if (rc) return rc;
         s->sqbox_valid[level] = true;
+        s->sqbox_kind[level] = kind;
     }
     return GME_OK;
 }
@@ -493,8 +495,8 @@ extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, i
     job.H = s->H; job.W = s->W; job.pitch = p.pitch;
     job.bs = bs; job.sw = sw; job.procedure = procedure; job.pnorm = pnorm;
     job.mf = s->mv; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
-    if (bbme_wants_sqbox(bs, sw, procedure, pnorm)) {
-        rc = seq_sqbox(s, 2);
+    if (const int aux = bbme_aux_kind(bs, sw, procedure, pnorm)) {
+        rc = seq_sqbox(s, 2, aux);
         if (rc) return rc;
         job.sqbox_cur = s->sqbox[2] + (size_t)fd * p.stride;
         job.sqbox_stride = p.stride;
@@ -597,8 +599,8 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
         job.pnorm = GME_NORM_MSE;
         job.mf = s->fit[l].gt; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
         if (s->fit[l].h == 0 || s->fit[l].w == 0) continue;
-        if (bbme_wants_sqbox(job.bs, job.sw, job.procedure, job.pnorm)) {      // BASELINE config 4
-            rc = seq_sqbox(s, l);
+        if (const int aux = bbme_aux_kind(job.bs, job.sw, job.procedure, job.pnorm)) {      // BASELINE config 4
+            rc = seq_sqbox(s, l, aux);
             if (rc) return rc;
             job.sqbox_cur = s->sqbox[l] + (size_t)fd * p.stride;
             job.sqbox_stride = p.stride;

@@ -83,6 +83,7 @@ struct gme_seq {
     uint32_t* sqbox[3] = { nullptr, nullptr, nullptr };   // per level: 16x16 box sums of squares per frame (MSE fast path)
     size_t sqbox_bytes[3] = { 0, 0, 0 };
     bool sqbox_valid[3] = { false, false, false };
+    int sqbox_kind[3] = { 0, 0, 0 };
     uint32_t* sqtmp = nullptr;    // row-pass scratch, sized for the largest level in use
     size_t sqtmp_bytes = 0;
     // GME state
@@ -119,8 +120,13 @@ struct BbmeJob {
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
                    uint32_t* tmp, uint32_t* out, long long stride);
-// true when launch_bbme would take the fast exhaustive-MSE kernel if given a box table
-bool bbme_wants_sqbox(int bs, int sw, int procedure, int pnorm);
+// per-frame auxiliary table a fast exhaustive kernel wants for `cur` (BbmeJob::sqbox_cur):
+// 0 none, 1 = 16x16 box sums of squares (MSE, k_exh_dot16)
+int bbme_aux_kind(int bs, int sw, int procedure, int pnorm);
+int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
+                     int pitch, uint32_t* tmp, uint32_t* out, long long stride);
+bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm);
+
 int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
 
 // ---- gme_kernels.hip --------------------------------------------------------

@@ -470,3 +470,24 @@ def test_gme_block_size_24_follows_float32_order(mods):
         motion.BBME_BLOCK_SIZE = old
     want = o.global_motion_estimation(prev, cur, block_size=24)
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+
+
+def test_successive_elimination_equals_brute_force(golden, mods, monkeypatch):
+    """k_exh_sea16 prunes candidates by exact lower bounds; GME_EXH_BRUTE=1 selects the plain
+    k_exh_qsad16.  Both must give the reference's field on real, synthetic and tie-heavy frames."""
+    native, bbme, _, _ = mods
+    import synth
+    g3 = golden("g3_docframes")
+    rng = np.random.default_rng(12)
+    flat = np.full((80, 112), 128, np.uint8)
+    quant = (rng.integers(0, 4, (96, 144)) * 64).astype(np.uint8)
+    cases = [(g3["in_race_prev"], g3["in_race_cur"], 16), (g3["in_pan240_prev"], g3["in_pan240_cur"], 8),
+             (synth.frame(5, 0, 270, 480), synth.frame(5, 3, 270, 480), 32), (flat, flat, 16),
+             (quant, np.roll(quant, (3, -5), (0, 1)), 12), (synth.frame(6, 0, 50, 70), synth.frame(6, 1, 50, 70), 4)]
+    sea = [bbme.get_motion_field(p, c, 16, sw, 0, 0) for p, c, sw in cases]
+    monkeypatch.setenv("GME_EXH_BRUTE", "1")
+    for (p, c, sw), want in zip(cases, sea):
+        assert np.array_equal(bbme.get_motion_field(p, c, 16, sw, 0, 0), want), sw
+    co = c_oracle()
+    for (p, c, sw), want in list(zip(cases, sea))[2:]:
+        assert np.array_equal(co.bbme(p, c, 16, sw, 0, 0), want), sw
