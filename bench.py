@@ -207,12 +207,25 @@ def main():
                        "sharding": "frame pairs across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_exh_sea16<3> (+ k_box8_* table build)" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
+                         "kernel": "k_exh_sea16<3>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
                                    ("whole step (all kernels + host solves)" if gme else "see DESIGN.md"),
                          "kernel_ms_per_launch": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "parity_first_pair_vs_reference_golden": parity,
         }
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) KB, the x2 being the guide's gfx950
+        # FETCH_SIZE correction, which the L2 miss count (TCC_MISS x 128 B) confirms here.
+        prof = os.path.join(REPO, "profiles", "r01_final_exh720_pmc_summary.txt")
+        if args.config == "exh720" and B == 512 and os.path.exists(prof):
+            vals = {}
+            for line in open(prof):
+                f = line.split()
+                if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[f[1]] = float(f[-1].split("=")[1])
+            if len(vals) == 2:
+                out["roofline"]["traffic"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e9
+                out["roofline"]["traffic_unit"] = "GB per launch, from profiles/r01_final_exh720_pmc_summary.txt"
         if proc == 0:
             ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
             # brute-force-equivalent rate: the exhaustive search's nominal byte abs-diffs per second.

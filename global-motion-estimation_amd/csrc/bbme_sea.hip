@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 }
 
 template <int R>
-__global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
+__global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
     const int NB = d.nb, T = blockDim.x;
@@ -68,8 +68,7 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
     uint32_t* count = best + NB;                           // [1]
     const int head = d.win_rows * d.pitch_dw + NB * 64 + NB + 1;
     uint64_t* s8 = (uint64_t*)(lds + ((head + 1) & ~1));   // [NC+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3), 8-byte aligned
-    uint32_t* work = (uint32_t*)(s8 + (16 * R + 8) * XQ);  // [NB*64*R] entries (s8 holds 16R+8 rows)
-    uint32_t* worklb = work + NB * 64 * R;                 // [NB*64*R] their lower bounds
+    uint32_t* work = (uint32_t*)(s8 + (16 * R + 8) * XQ);  // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
 
     const int b = blockIdx.x;
     const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
@@ -112,12 +111,15 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
         const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
         anchor[wave * 64 + lane] = mine;
-        const uint32_t s = __builtin_amdgcn_sad_u8(mine, 0u, 0u);       // sum of this lane's 4 bytes
-        const int quad = ((lane >> 5) << 1) | ((lane >> 1) & 1);        // (row >= 8) * 2 + (col >= 8)
-        const uint32_t q0 = wave_sum_u32(quad == 0 ? s : 0u), q1 = wave_sum_u32(quad == 1 ? s : 0u);
-        const uint32_t q2 = wave_sum_u32(quad == 2 ? s : 0u), q3 = wave_sum_u32(quad == 3 ? s : 0u);
-        a01 = q0 | (q1 << 16);
-        a23 = q2 | (q3 << 16);
+        // quadrant sums: lane = (row, dword); xor 1 pairs the two dwords of a half row, xor 4/8/16
+        // sums the 8 rows of a half -> lanes 0, 2, 32, 34 hold the four 8x8 sums
+        uint32_t s = __builtin_amdgcn_sad_u8(mine, 0u, 0u);             // sum of this lane's 4 bytes
+        s += (uint32_t)__shfl_xor((int)s, 1, 64);
+        s += (uint32_t)__shfl_xor((int)s, 4, 64);
+        s += (uint32_t)__shfl_xor((int)s, 8, 64);
+        s += (uint32_t)__shfl_xor((int)s, 16, 64);
+        a01 = (uint32_t)__builtin_amdgcn_readlane((int)s, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 2) << 16);
+        a23 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 34) << 16);
     }
     if (threadIdx.x == 0) *count = 0;
     __syncthreads();
@@ -155,7 +157,11 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
     uint32_t ub_key = 0xFFFFFFFFu;
     if (wave_ok) {
         const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
-        uint32_t lb_key = 0xFFFFFFFFu;                     // (LB << 13 | scan index) of the lane's best bound
+        // per patch k: min over its candidates of (LB << 13) + local, local = (4k+e)*R + i (any
+        // consistent index will do here: the bound only has to name one good candidate)
+        uint32_t pkey[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
         const bool interior = lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -169,29 +175,42 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
                 const uint64_t ta = sp[0], tb = sp[2], ba = sp[8 * XQ], bb = sp[8 * XQ + 2];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int ci = ci0 + e;
-                    if (!interior && (ci < lo_c || ci > hi_c)) continue;
+                    if (!interior && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
                     const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
                     const uint32_t top = __builtin_amdgcn_perm((uint32_t)(tb >> (32 * (e >> 1))), (uint32_t)(ta >> (32 * (e >> 1))), sel);
                     const uint32_t bot = __builtin_amdgcn_perm((uint32_t)(bb >> (32 * (e >> 1))), (uint32_t)(ba >> (32 * (e >> 1))), sel);
                     const uint32_t lb = __builtin_amdgcn_sad_u16(top, a01, __builtin_amdgcn_sad_u16(bot, a23, 0u));
-                    patch_lb[k] = min(patch_lb[k], lb);
-                    lb_key = min(lb_key, (lb << 13) | (uint32_t)(ci * NC + ri));
+                    pkey[k] = min(pkey[k], (lb << 13) + (uint32_t)((4 * k + e) * R + i));
                 }
             }
         }
+        uint32_t lb_key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (pkey[k] != 0xFFFFFFFFu) patch_lb[k] = pkey[k] >> 13;
+            lb_key = min(lb_key, pkey[k]);
+        }
+        if (lb_key != 0xFFFFFFFFu) lb_key += (uint32_t)lane << 7;      // local < 4R*R <= 100 < 128
         // ---- C: upper bound from two real candidates (cooperative 16x16 SAD, one dword per lane)
         lb_key = wave_min_u32(lb_key);
-        const int arow = lane >> 2, aj = lane & 3;
+        {
+            const int bl = (lb_key >> 7) & 63, loc = lb_key & 127;     // decode lane and local index
+            const int ce = loc / R, li = loc - ce * R;
+            const int idx1 = ((bl & 3) * 4 * R + ce) * NC + (bl >> 2) * R + li;       // min-LB candidate
+            const int idx0 = d.sw * NC + d.sw;                                       // zero vector
+            const int arow = lane >> 2, aj = lane & 3;
+            uint32_t packed = 0;                           // two 16x16 SADs (<= 65280 each) in one register
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const int idx = which == 0 ? (int)(lb_key & 0x1FFF) : d.sw * NC + d.sw;     // min-LB candidate, zero vector
-            const int ci = idx / NC, ri = idx - ci * NC;
-            const int byte = wave * 16 + ci + 4 * aj;
-            const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
-            const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
-            const uint32_t sad = wave_sum_u32(__builtin_amdgcn_sad_u8(v, mine, 0u));
-            ub_key = min(ub_key, (sad << 13) | (uint32_t)idx);
+            for (int which = 0; which < 2; ++which) {
+                const int idx = which ? idx1 : idx0;
+                const int ci = idx / NC, ri = idx - ci * NC;
+                const int byte = wave * 16 + ci + 4 * aj;
+                const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
+                const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
+                packed += __builtin_amdgcn_sad_u8(v, mine, 0u) << (16 * which);
+            }
+            packed = wave_sum_u32(packed);
+            ub_key = min(((packed & 0xFFFFu) << 13) | (uint32_t)idx0, ((packed >> 16) << 13) | (uint32_t)idx1);
         }
         if (lane == 0) best[wave] = ub_key;
         // ---- D: surviving patches -> workgroup list
@@ -200,8 +219,7 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
         for (int k = 0; k < R; ++k)
             if (patch_lb[k] <= ub) {
                 const uint32_t slot = atomicAdd(count, 1u);
-                work[slot] = ((uint32_t)wave << 16) | ((uint32_t)lane << 4) | (uint32_t)k;
-                worklb[slot] = patch_lb[k];
+                work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];   // LB <= 65280
             }
     }
     __syncthreads();
@@ -214,10 +232,10 @@ __global__ void __launch_bounds__(384) k_exh_sea16(SeaDev d)
         uint32_t ent = 0;
         if (active) {
             ent = work[e];
-            active = worklb[e] <= (best[ent >> 16] >> 13);             // dropped by a tightened UB
+            active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
         }
         if (active) {
-            const int w2 = ent >> 16, l2 = (ent >> 4) & 63, k2 = ent & 15;
+            const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
             const int prow2 = l2 >> 2, q2 = l2 & 3;
             const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
             const uint32_t* an = anchor + w2 * 64;
@@ -302,19 +320,37 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
-    int nb = 4;
-    for (int cand : {5, 4, 6, 3}) if (nbc % cand == 0) { nb = cand; break; }
-    if (nbc < nb) nb = nbc;
+    // Waves (= macroblocks) per workgroup.  More blocks share more of the staged window and of the
+    // box-sum pass, but LDS per workgroup grows; pick the count that keeps most waves resident per
+    // CU (160 KiB LDS, 32 waves), discounted by the idle waves of a ragged last workgroup.
+    auto lds_bytes = [&](int nb_, int* pitch_out, int* xq_out) {
+        const int xq = (4 * R + 4 * (nb_ - 1) + 2) | 1;                 // S8 quads per row, odd pitch
+        const int need_dw = (nb_ - 1) * 4 + 3 * R + (R - 1) + 5;        // base + k + 4 pairs of two dwords
+        const int pitch = pick_pitch_sea(need_dw > xq + 2 ? need_dw : xq + 2, R);
+        const size_t head = (size_t)(16 * R + 15) * pitch + (size_t)nb_ * 64 + nb_ + 1;
+        if (pitch_out) *pitch_out = pitch;
+        if (xq_out) *xq_out = xq;
+        return (((head + 1) & ~(size_t)1) + 2 * (size_t)(16 * R + 8) * xq + (size_t)nb_ * 64 * R) * 4;
+    };
+    int nb = 0;
+    double best_score = -1.0;
+    for (int cand = 1; cand <= 16 && cand <= nbc; ++cand) {
+        const size_t bytes = lds_bytes(cand, nullptr, nullptr);
+        if (bytes > 160 * 1024) break;
+        const int wgs = (int)((160 * 1024) / (bytes + 1024));           // allocation granularity slack
+        const int waves = wgs * cand > 32 ? 32 : wgs * cand;
+        const int per_row = (nbc + cand - 1) / cand;
+        const double score = waves * ((double)nbc / (per_row * cand)) + cand * 1e-3 + (nbc % cand == 0 ? 0.05 : 0.0);
+        if (score > best_score) { best_score = score; nb = cand; }
+    }
+    if (const char* e = getenv("GME_SEA_NB")) nb = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
+    if (nb > nbc) nb = nbc;
+    GME_REQUIRE(nb >= 1, GME_ERR_ARG, "search window too large for LDS");
     d.nb = nb;
     d.wg_per_row = (nbc + nb - 1) / nb;
     d.wg_per_pair = d.wg_per_row * nbr;
     d.win_rows = 16 * R + 15;
-    const int need_dw = (nb - 1) * 4 + 3 * R + (R - 1) + 5;    // base + k + 4 pairs of two dwords
-    d.xq = (4 * R + 4 * (nb - 1) + 2) | 1;                     // S8 columns 0 .. 16R + 16(nb-1) + 7; odd row pitch
-    d.pitch_dw = pick_pitch_sea(need_dw > d.xq + 2 ? need_dw : d.xq + 2, R);
-    const size_t work_dw = 2 * (size_t)nb * 64 * R;
-    const size_t head = (size_t)d.win_rows * d.pitch_dw + (size_t)nb * 64 + nb + 1;
-    const size_t lds = (((head + 1) & ~(size_t)1) + 2 * (size_t)(16 * R + 8) * d.xq + work_dw) * 4;
+    const size_t lds = lds_bytes(nb, &d.pitch_dw, &d.xq);
     GME_REQUIRE(lds <= 160 * 1024, GME_ERR_ARG, "search window too large for LDS");
     const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
     GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
