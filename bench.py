@@ -119,16 +119,29 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GME_BENCH_FORCE_DIST"):      # the latter rehearses RCCL with one rank
         import torch.distributed as dist
         ndev = torch.cuda.device_count()
         local = local % max(ndev, 1)               # rehearsals may put several ranks on one card
         torch.cuda.set_device(local)
         backend = os.environ.get("GME_BENCH_BACKEND", "nccl")      # nccl = RCCL; gloo only for rehearsal
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout when it initialises; stdout must carry the one
+        # JSON line only, so park fd 1 on stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if dist is not None:

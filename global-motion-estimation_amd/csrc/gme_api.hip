@@ -529,7 +529,7 @@ static int alloc_fit(FitLevelBuf& f, int pairs, int h, int w, bool full)
         ok = ok && hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.mask, n) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.diff, n * sizeof(int32_t)) == hipSuccess;
-        if ((size_t)h * w * 16 > 64 * 1024) ok = ok && hipMalloc(&f.list, n * 16) == hipSuccess;
+        if ((size_t)h * w * 16 > 40 * 1024) ok = ok && hipMalloc(&f.list, n * 16) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.thr, (size_t)pairs * sizeof(int32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&f.sums, (size_t)pairs * 15 * sizeof(double)) == hipSuccess;
     }
@@ -635,7 +635,7 @@ static int ensure_fit_mv(gme_seq* s)
     const size_t n = (size_t)s->mv_pairs * f.h * f.w;
     if (hipMalloc((void**)&f.model, n * 2 * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&f.mask, n) != hipSuccess ||
         hipMalloc((void**)&f.diff, n * sizeof(int32_t)) != hipSuccess ||
-        ((size_t)f.h * f.w * 16 > 64 * 1024 && hipMalloc(&f.list, n * 16) != hipSuccess) ||
+        ((size_t)f.h * f.w * 16 > 40 * 1024 && hipMalloc(&f.list, n * 16) != hipSuccess) ||
         hipMalloc((void**)&f.thr, (size_t)s->mv_pairs * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void**)&f.sums, (size_t)s->mv_pairs * 15 * sizeof(double)) != hipSuccess) {
         gme_set_error("out of device memory (fit buffers)");

@@ -211,36 +211,37 @@ __global__ void __launch_bounds__(256) k_fit_level(const int32_t* gt_all, int h,
     }
     const int m = list_base;
 
-    // sequential float64 sums over inliers in row-major order (motion.py:248-261,266-279);
-    // twelve independent chains, one per lane: F00 F01 F02 F11 F12 F22 | Sx0..2 | Sy0..2.
-    // The list makes the loop branch-free, so its loads pipeline ahead of the add chain.
+    // sequential float64 sums over inliers in row-major order (motion.py:248-261,266-279):
+    // twelve independent chains F00 F01 F02 F11 F12 F22 | Sx0..2 | Sy0..2.  Only the additions
+    // are order sensitive, so all 256 threads form the terms (product * w, rounded like the
+    // reference) of 256 list entries at a time into LDS, then twelve lanes add them in list order.
+    __shared__ double terms[12][256];
+    const int fa[6] = { 0, 0, 0, 1, 1, 2 }, fb[6] = { 0, 1, 2, 1, 2, 2 };
+    double acc = 0.0;
+    for (int e0 = 0; e0 < m; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        if (e < m) {
+            const int4 v = list[e];
+            const double one = 1.0, x = (double)v.x, y = (double)v.y, g0 = (double)v.z, g1 = (double)v.w;
+            const double va[3] = { one, x, y };
+#pragma unroll
+            for (int c = 0; c < 6; ++c) terms[c][threadIdx.x] = __dmul_rn(__dmul_rn(va[fa[c]], va[fb[c]]), wgt);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                terms[6 + a][threadIdx.x] = __dmul_rn(__dmul_rn(va[a], g0), wgt);
+                terms[9 + a][threadIdx.x] = __dmul_rn(__dmul_rn(va[a], g1), wgt);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const int cnt = min(256, m - e0);
+            const double* t = terms[threadIdx.x];
+            for (int u = 0; u < cnt; ++u) acc = __dadd_rn(acc, t[u]);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < 12) {
         const int c = threadIdx.x;
-        const int fa[6] = { 0, 0, 0, 1, 1, 2 }, fb[6] = { 0, 1, 2, 1, 2, 2 };
-        const int a = c < 6 ? fa[c] : (c - 6) % 3;
-        const int b = c < 6 ? fb[c] : (c < 9 ? 3 : 4);          // 3, 4: the two motion-vector channels
-        double acc = 0.0;
-        // terms of 8 entries are formed independently (loads, converts, two multiplies pipeline),
-        // then added to the chain one by one in list order -- only the adds are serial
-        int e = 0;
-        for (; e + 8 <= m; e += 8) {
-            double term[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int4 v = list[e + u];
-                const int va = a == 0 ? 1 : (a == 1 ? v.x : v.y);
-                const int vb = b == 0 ? 1 : (b == 1 ? v.x : (b == 2 ? v.y : (b == 3 ? v.z : v.w)));
-                term[u] = __dmul_rn(__dmul_rn((double)va, (double)vb), wgt);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, term[u]);
-        }
-        for (; e < m; ++e) {
-            const int4 v = list[e];
-            const int va = a == 0 ? 1 : (a == 1 ? v.x : v.y);
-            const int vb = b == 0 ? 1 : (b == 1 ? v.x : (b == 2 ? v.y : (b == 3 ? v.z : v.w)));
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)va, (double)vb), wgt));
-        }
         double* s = sums_all + (long long)pair * 15;
         if (c < 6) { s[fa[c] * 3 + fb[c]] = acc; s[fb[c] * 3 + fa[c]] = acc; }
         else s[9 + (c - 6)] = acc;
@@ -407,7 +408,7 @@ int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, c
     const double wgt = 1.0 / ((double)level_H * (double)level_W);      // motion.py:250
     // inlier list: LDS when it fits beside a second resident workgroup, else the global buffer
     const size_t need = (size_t)h * w * sizeof(int4);
-    const int in_lds = need <= 64 * 1024;
+    const int in_lds = need <= 40 * 1024;
     hipLaunchKernelGGL(k_fit_level, dim3(pairs), dim3(256), in_lds ? need : 0, ctx->stream, gt, h, w, params, drop, wgt,
                        model, mask, diff, thr, sums, (int4*)list, in_lds);
     GME_HIP_TRY(hipGetLastError());

@@ -491,3 +491,29 @@ def test_successive_elimination_equals_brute_force(golden, mods, monkeypatch):
     co = c_oracle()
     for (p, c, sw), want in list(zip(cases, sea))[2:]:
         assert np.array_equal(co.bbme(p, c, 16, sw, 0, 0), want), sw
+
+
+@pytest.mark.parametrize("pnorm", [0, 1])
+def test_full_size_properties_1080p(mods, pnorm):
+    """BASELINE-size checks that need no oracle run: on a 1920x1080 random texture a pure shift is
+    recovered by every interior block, identical frames give the zero field, and the batched
+    sequence path returns the same fields as the single-pair call."""
+    native, bbme, _, _ = mods
+    rng = np.random.default_rng(1080 + pnorm)
+    canvas = rng.integers(0, 256, (1080 + 64, 1920 + 64), dtype=np.uint8)
+    prev = np.ascontiguousarray(canvas[32:32 + 1080, 32:32 + 1920])
+    dx, dy = 23, -17                                   # content moves +23 columns, -17 rows
+    cur = np.ascontiguousarray(canvas[32 - dy:32 - dy + 1080, 32 - dx:32 - dx + 1920])
+    mf = bbme.get_motion_field(prev, cur, 16, 32, 0, pnorm)
+    assert mf.shape == (67, 120, 2)
+    inner = mf[3:-3, 3:-3].reshape(-1, 2)
+    assert (inner == (dx, dy)).all()
+    assert (bbme.get_motion_field(prev, prev, 16, 32, 0, pnorm) == 0).all()
+    for sp in (1, 2, 3):                               # walks start at the zero vector and stay there
+        assert (bbme.get_motion_field(prev, prev, 16, 32, sp, pnorm)[1:-1, 1:-1] == 0).all(), sp
+    seq = native.Sequence.from_frames(native.default_context(), [prev, cur, prev])
+    seq.bbme(1, 16, 32, 0, pnorm)
+    both = seq.read_mv()
+    assert np.array_equal(both[0], mf)
+    assert (both[1][3:-3, 3:-3].reshape(-1, 2) == (-dx, -dy)).all()
+    seq.close()
