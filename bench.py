@@ -41,6 +41,10 @@ CONFIGS = {
     "exh1080mse": (1080, 1920, 16, 32, 0, 1, 4321, "1920x1080 synthetic luma, bs=16 sw=32 exhaustive MSE"),
     "gme1080exh": (1080, 1920, 16, 32, -2, 1, 4321, "1920x1080 synthetic, bs=16 sw=32 exhaustive MSE + affine fit "
                    "(BASELINE configs[3]: GME with exhaustive BBME at levels 1-2) + compensate"),
+    # BASELINE configs[4]: the whole 2000-frame 1080p sequence, sharded over the ranks by pair range,
+    # diamond GME + compensation per pair, one all-gather of the float64[6] rows at the end of a step
+    "seq1080": (1080, 1920, 16, 2, -3, 1, 2000, "2000-frame 1920x1080 synthetic sequence sharded across the GPUs, "
+                "diamond-search GME + compensate + PSNR, RCCL all-gather of per-pair parameters (BASELINE configs[4])"),
     "gme1080": (1080, 1920, 16, 2, -1, 1, 2000, "1920x1080 synthetic sequence, diamond-search GME + compensate, "
                 "BASELINE configs[4] per-GPU shard"),
 }
@@ -152,12 +156,33 @@ def main():
     import _gme_native as native
     ctx = native.Context(local)
     B = args.pairs
-    seq = native.Sequence(ctx, B + 1, H, W)
-    seq.synth(seed, rank * B)                      # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
+    if proc == -3:
+        import sequence
+        n_frames = int(os.environ.get("GME_BENCH_FRAMES", "2000"))
+        shard = sequence.ShardedSequence(H, W, n_frames, 1, rank=rank, world=world, ctx=ctx)
+        shard.synth(seed)                          # each rank generates its own slice (pairs + 1 halo frame)
+        seq = shard.seq
+        B = shard.n_pairs                          # pairs of THIS rank; the step covers the whole sequence
+    else:
+        seq = native.Sequence(ctx, B + 1, H, W)
+        seq.synth(seed, rank * B)                  # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
     ctx.sync()
 
     gme = proc < 0
-    if gme:
+    if proc == -3:
+        import motion
+        last = {}
+        gather_dev = torch.device("cuda", local) if (dist is not None and dist.get_backend() == "nccl") else None
+
+        def step():
+            seq.invalidate_pyramids()
+            params = shard.estimate()
+            psnr = shard.compensate(params)
+            rows = np.concatenate([params, psnr[:, None]], axis=1)
+            if dist is not None:                   # the path's one exchange: 56 B per pair over RCCL
+                rows = sequence.gather_parameters(rows, shard.n_pairs_total, rank, dist.get_world_size(), gather_dev)
+            last["rows"] = rows
+    elif gme:
         import motion
         last = {}
 
@@ -206,9 +231,14 @@ def main():
                       and comp_sha == str(g4["synth720_comp_sha"]))
 
     if rank == 0:
-        total_pairs = world * B * args.steps
+        total_pairs = (shard.n_pairs_total if proc == -3 else world * B) * args.steps
         value = total_pairs / elapsed
         abytes = algorithmic_bytes(H, W, bs, gme) * B
+        if proc == -3:
+            rows = last["rows"]
+            out_extra = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),
+                         "mean_psnr_db": float(np.mean(rows[:, 6])),
+                         "median_params": [float(x) for x in np.median(rows[:, :6], axis=0)]}
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive, 1->8 GPU"
@@ -246,6 +276,8 @@ def main():
             # exceed the instruction-issue ceiling of a brute-force kernel (frac > 1).
             out["valu"] = {"bound": "v_qsad_pk_u16_u8 issue (brute-force equivalent)", "achieved": ops,
                            "peak": QSAD_PEAK_OPS, "unit": "byte-abs-diff/s", "frac": ops / QSAD_PEAK_OPS}
+        if proc == -3:
+            out["sequence"] = out_extra
         if world == 1 and not args.no_cpu_baseline and proc == 0:
             cb = cpu_baseline(cfg)
             rows, ref_mf = cb.pop("rows_checked"), cb.pop("mf")

@@ -37,7 +37,16 @@ struct SeaDev {
     int pitch_dw, win_rows;
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
+#ifdef GME_SEA_STAMPS
+    long long* stamps;            // diagnostic build only (tools/microbench/sea_phases.hip): 8 per wave
+#endif
 };
+
+#ifdef GME_SEA_STAMPS
+#define STAMP(i) do { if (lane == 0) d.stamps[((long long)blockIdx.x * NB + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
 typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
@@ -56,7 +65,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-template <int R>
+template <int R, bool E4>
 __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
@@ -86,6 +95,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     const int c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
 
+    STAMP(0);
     // ---- A: window, anchor, quadrant sums ------------------------------------------------
     {
         const int gx0 = bcol0 * 16 - d.sw, gy0 = r0 - d.sw;
@@ -94,15 +104,23 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
         const int gx = gx0 + 4 * dw;
         const bool colok = gx >= 0 && gx < d.pitch;
         if (row0 < rstep) {
+            // batches of 4 independent loads, then 4 LDS stores: a plain load/store loop makes the
+            // compiler wait for every load before it issues the next one (one L2 latency per row)
             const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
             const long long sstep = (long long)rstep * d.pitch;
             uint32_t* dst = win + row0 * d.pitch_dw + dw;
             const int dstep = rstep * d.pitch_dw;
-            for (int row = row0; row < d.win_rows; row += rstep, src += sstep, dst += dstep) {
-                const int gy = gy0 + row;
-                uint32_t v = 0;
-                if (colok && gy >= 0 && gy < d.H) v = *(const uint32_t*)src;
-                *dst = v;
+            for (int row = row0; row < d.win_rows; row += 4 * rstep, src += 4 * sstep, dst += 4 * dstep) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int gy = gy0 + row + u * rstep;
+                    v[u] = 0;
+                    if (colok && row + u * rstep < d.win_rows && gy >= 0 && gy < d.H) v[u] = *(const uint32_t*)(src + u * sstep);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (row + u * rstep < d.win_rows) dst[u * dstep] = v[u];
             }
         }
     }
@@ -122,7 +140,9 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
         a23 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 34) << 16);
     }
     if (threadIdx.x == 0) *count = 0;
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     // ---- A': 8x8 box sums of the window ---------------------------------------------------------
     // Thread (column quad sq, row chunk ch) walks CH+7 window rows: per row two QSADs against a
@@ -147,7 +167,9 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
             }
         }
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
 
     // ---- B: lower bounds of the wave's own block --------------------------------------------
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
@@ -222,60 +244,138 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
                 work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];   // LB <= 65280
             }
     }
+    STAMP(5);
     __syncthreads();
+    STAMP(6);
 
-    // ---- E: evaluate the listed patches, one per lane ---------------------------------------
-    const int n = (int)*count;
-    for (int base = 0; base < n; base += T) {
-        const int e = base + threadIdx.x;
-        bool active = e < n;
-        uint32_t ent = 0;
-        if (active) {
-            ent = work[e];
-            active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
-        }
-        if (active) {
+    if constexpr (E4) {
+        // ---- E (variant): four lanes per patch ---------------------------------------------------
+        // Lane `sub` of a quad takes anchor rows 4*sub .. 4*sub+3 (R+3 window rows, 16*R QSADs); the four
+        // partial u16x4 sums are added inside the quad with DPP moves.
+        const int n = (int)*count;
+        const int sub = lane & 3;
+        for (int base = 0; base < n; base += T / 4) {
+            const int e = base + (threadIdx.x >> 2);
+            bool active = e < n;
+            uint32_t ent = 0;
+            if (active) {
+                ent = work[e];
+                active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
+            }
+            // the quad is uniform in `active` (same entry), so the DPP exchange below is safe
             const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
             const int prow2 = l2 >> 2, q2 = l2 & 3;
-            const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
-            const uint32_t* an = anchor + w2 * 64;
             uint64_t acc[R];
-#pragma unroll
+    #pragma unroll
             for (int i = 0; i < R; ++i) acc[i] = 0;
-#pragma unroll
-            for (int t = 0; t < R + 15; ++t) {
-                uint64_t w[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int a = t - i;
-                    if (a < 0 || a > 15) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+            if (active) {
+                const uint32_t* lrow = win + (prow2 * R + 4 * sub) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+                const uint32_t* an = anchor + w2 * 64 + 16 * sub;
+    #pragma unroll
+                for (int t = 0; t < R + 3; ++t) {
+                    uint64_t w[4];
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
+    #pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int a = t - i;                   // anchor row 4*sub + a
+                        if (a < 0 || a > 3) continue;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+                    }
                 }
             }
-            const int c02 = (bcol0 + w2) * 16;
-            const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
-            uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int ci = q2 * 4 * R + 4 * k2 + e4;
-                if (ci < lo_c || ci > hi_c) continue;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int ri = prow2 * R + i;
-                    if (ri < lo_r || ri > hi_r) continue;
-                    const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
-                    key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
-                }
+            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    #pragma unroll
+            for (int i = 0; i < R; ++i) {
+                uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+                uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+                lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, lo) + __builtin_bit_cast(u16x2, olo));
+                hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hi) + __builtin_bit_cast(u16x2, ohi));
+                olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);            // quad_perm [2,3,0,1]
+                ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+                lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, lo) + __builtin_bit_cast(u16x2, olo));
+                hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hi) + __builtin_bit_cast(u16x2, ohi));
+                acc[i] = ((uint64_t)hi << 32) | lo;
             }
-            if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+            if (active && sub == 0) {
+                const int c02 = (bcol0 + w2) * 16;
+                const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                uint32_t key = 0xFFFFFFFFu;
+    #pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int ci = q2 * 4 * R + 4 * k2 + e4;
+                    if (ci < lo_c || ci > hi_c) continue;
+    #pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int ri = prow2 * R + i;
+                        if (ri < lo_r || ri > hi_r) continue;
+                        const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                        key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                    }
+                }
+                if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
 
+    } else {
+        // ---- E: evaluate the listed patches, one per lane ---------------------------------------
+        const int n = (int)*count;
+        for (int base = 0; base < n; base += T) {
+            const int e = base + threadIdx.x;
+            bool active = e < n;
+            uint32_t ent = 0;
+            if (active) {
+                ent = work[e];
+                active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
+            }
+            if (active) {
+                const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+                const int prow2 = l2 >> 2, q2 = l2 & 3;
+                const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+                const uint32_t* an = anchor + w2 * 64;
+                uint64_t acc[R];
+    #pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = 0;
+    #pragma unroll
+                for (int t = 0; t < R + 15; ++t) {
+                    uint64_t w[4];
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
+    #pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int a = t - i;
+                        if (a < 0 || a > 15) continue;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+                    }
+                }
+                const int c02 = (bcol0 + w2) * 16;
+                const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                uint32_t key = 0xFFFFFFFFu;
+    #pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int ci = q2 * 4 * R + 4 * k2 + e4;
+                    if (ci < lo_c || ci > hi_c) continue;
+    #pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int ri = prow2 * R + i;
+                        if (ri < lo_r || ri > hi_r) continue;
+                        const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                        key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                    }
+                }
+                if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+            }
+            __syncthreads();
+        }
+
+    }
+    STAMP(7);
     // ---- F: result ------------------------------------------------------------------------------
     if (wave_ok && lane == 0) {
         const int idx = (int)(best[wave] & 0x1FFF);
@@ -309,6 +409,10 @@ bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm)
     return (NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC") && !getenv("GME_EXH_BRUTE");
 }
 
+#ifdef GME_SEA_STAMPS
+static long long* g_stamps = nullptr;
+#endif
+
 int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
 {
     *handled = false;
@@ -320,6 +424,9 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
+#ifdef GME_SEA_STAMPS
+    d.stamps = g_stamps;
+#endif
     // Waves (= macroblocks) per workgroup.  More blocks share more of the staged window and of the
     // box-sum pass, but LDS per workgroup grows; pick the count that keeps most waves resident per
     // CU (160 KiB LDS, 32 waves), discounted by the idle waves of a ragged last workgroup.
@@ -355,13 +462,17 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
     GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
     const dim3 grid((unsigned)groups), block(64 * nb);
+    const bool e4 = getenv("GME_SEA_E4") != nullptr;           // A/B switch for phase E (4 lanes per patch)
+#define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
+                            else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
     switch (R) {
-    case 1: hipLaunchKernelGGL(k_exh_sea16<1>, grid, block, lds, ctx->stream, d); break;
-    case 2: hipLaunchKernelGGL(k_exh_sea16<2>, grid, block, lds, ctx->stream, d); break;
-    case 3: hipLaunchKernelGGL(k_exh_sea16<3>, grid, block, lds, ctx->stream, d); break;
-    case 4: hipLaunchKernelGGL(k_exh_sea16<4>, grid, block, lds, ctx->stream, d); break;
-    default: hipLaunchKernelGGL(k_exh_sea16<5>, grid, block, lds, ctx->stream, d); break;
+    case 1: SEA_LAUNCH(1); break;
+    case 2: SEA_LAUNCH(2); break;
+    case 3: SEA_LAUNCH(3); break;
+    case 4: SEA_LAUNCH(4); break;
+    default: SEA_LAUNCH(5); break;
     }
+#undef SEA_LAUNCH
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
     return GME_OK;

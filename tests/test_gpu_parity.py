@@ -517,3 +517,31 @@ def test_full_size_properties_1080p(mods, pnorm):
     assert np.array_equal(both[0], mf)
     assert (both[1][3:-3, 3:-3].reshape(-1, 2) == (-dx, -dy)).all()
     seq.close()
+
+
+def test_exhaustive_bs16_random_geometries(mods):
+    """Randomised sweep of the two fast exhaustive kernels (successive elimination for MAE, dot4 for
+    MSE) over frame sizes from one block up, windows 0..36 and tie-heavy content, vs the C oracle."""
+    _, bbme, _, _ = mods
+    co = c_oracle()
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        H, W = int(rng.integers(16, 150)), int(rng.integers(16, 260))
+        sw = int(rng.choice([0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 5, 7]))
+        kind = trial % 4
+        if kind == 0:
+            p, c = rng.integers(0, 256, (H, W), dtype=np.uint8), rng.integers(0, 256, (H, W), dtype=np.uint8)
+        elif kind == 1:
+            base = rng.integers(0, 256, (H + 40, W + 40), dtype=np.uint8)
+            dy, dx = int(rng.integers(-9, 10)), int(rng.integers(-9, 10))
+            p, c = base[20:20 + H, 20:20 + W], base[20 + dy:20 + dy + H, 20 + dx:20 + dx + W]
+        elif kind == 2:
+            p = (rng.integers(0, 3, (H, W)) * 100).astype(np.uint8)
+            c = np.roll(p, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (0, 1))
+        else:
+            p = np.full((H, W), int(rng.integers(0, 256)), np.uint8)
+            c = p.copy()
+        p, c = np.ascontiguousarray(p), np.ascontiguousarray(c)
+        for pn in (0, 1):
+            got = bbme.get_motion_field(p, c, 16, sw, 0, pn)
+            assert np.array_equal(got, co.bbme(p, c, 16, sw, 0, pn)), (trial, H, W, sw, pn)
