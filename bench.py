@@ -244,7 +244,8 @@ def main():
             "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive, 1->8 GPU"
                       if args.config == "exh720" else "frame-pairs/s, " + args.config,
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if proc == -3 else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
                        "sharding": "frame pairs across ranks, no data-path collective"},

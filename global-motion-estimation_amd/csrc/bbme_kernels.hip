@@ -324,10 +324,32 @@ static bool needs_f32_order(int bs, int pnorm)
     return (double)bs * bs * (pnorm ? 65025.0 : 255.0) >= 16777216.0;
 }
 
+static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job);
+
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
 {
     int rc = bbme_check_args(job.H, job.W, job.bs, job.sw, job.procedure, job.pnorm);
     if (rc != GME_OK) return rc;
+    // long sequences: keep every launch below ~16 M blocks so grid sizes stay far from 2^31
+    const long long nblk = (long long)(job.H / job.bs) * (job.W / job.bs);
+    if (nblk == 0 || job.pairs == 0) return GME_OK;
+    const long long per = (1ll << 24) / nblk < 1 ? 1 : (1ll << 24) / nblk;
+    for (long long first = 0; first < job.pairs; first += per) {
+        BbmeJob part = job;
+        part.pairs = (int)(job.pairs - first < per ? job.pairs - first : per);
+        part.prev = job.prev + first * job.plane_stride;
+        part.cur = job.cur + first * job.plane_stride;
+        part.mf = job.mf + first * nblk * 2;
+        if (job.sqbox_cur) part.sqbox_cur = job.sqbox_cur + first * job.sqbox_stride;
+        rc = launch_bbme_chunk(ctx, part);
+        if (rc != GME_OK) return rc;
+    }
+    return GME_OK;
+}
+
+static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
+{
+    int rc = GME_OK;
     Dev d;
     d.f32 = needs_f32_order(job.bs, job.pnorm) ? 1 : 0;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
