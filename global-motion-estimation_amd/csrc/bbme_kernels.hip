@@ -316,6 +316,7 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm)
 
 int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled);
+int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 
 // the reference's float32 sums stop being exact integers at 2^24 (bbme.py:61-64)
@@ -363,6 +364,8 @@ static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
 
     bool handled = false;
     rc = launch_bbme_sea(ctx, job, &handled);
+    if (rc != GME_OK || handled) return rc;
+    rc = launch_bbme_sea_mse(ctx, job, &handled);
     if (rc != GME_OK || handled) return rc;
     rc = launch_bbme_fast(ctx, job, &handled);
     if (rc != GME_OK || handled) return rc;

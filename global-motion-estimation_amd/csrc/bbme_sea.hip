@@ -22,25 +22,11 @@
 //      the tightened UB are dropped;
 //   F  lane 0 of each wave stores its block's vector.
 // On the synthetic and the reference's doc frames 3-6 % of the patches survive.
-#include <stdlib.h>
-
-#include "gme_internal.h"
+#include "bbme_sea_common.h"
 
 namespace {
 
-struct SeaDev {
-    const uint8_t* prev;
-    const uint8_t* cur;
-    long long plane_stride;
-    int pairs, H, W, pitch, sw;
-    int nbr, nbc, nb, wg_per_row, wg_per_pair;
-    int pitch_dw, win_rows;
-    int32_t* mf;
-    int xq;                       // S8 quads (4 columns each) per window row
-#ifdef GME_SEA_STAMPS
-    long long* stamps;            // diagnostic build only (tools/microbench/sea_phases.hip): 8 per wave
-#endif
-};
+using namespace sea;
 
 #ifdef GME_SEA_STAMPS
 #define STAMP(i) do { if (lane == 0) d.stamps[((long long)blockIdx.x * NB + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -48,36 +34,19 @@ struct SeaDev {
 #define STAMP(i) do { } while (0)
 #endif
 
-typedef uint64_t u64_a4 __attribute__((aligned(4)));
-typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
-}
-
 template <int R, bool E4>
 __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
     const int NB = d.nb, T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
-    uint32_t* win = lds;                                   // [win_rows][pitch_dw]
-    uint32_t* anchor = win + d.win_rows * d.pitch_dw;      // [NB][64]
-    uint32_t* best = anchor + NB * 64;                     // [NB]
-    uint32_t* count = best + NB;                           // [1]
-    const int head = d.win_rows * d.pitch_dw + NB * 64 + NB + 1;
-    uint64_t* s8 = (uint64_t*)(lds + ((head + 1) & ~1));   // [NC+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3), 8-byte aligned
-    uint32_t* work = (uint32_t*)(s8 + (16 * R + 8) * XQ);  // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
+    const Layout L = make_layout(R, NB, d.win_rows, d.pitch_dw, XQ);
+    uint32_t* win = lds + L.win;                           // [win_rows][pitch_dw]
+    uint32_t* anchor = lds + L.anchor;                     // [NB][64]
+    uint32_t* best = lds + L.best;                         // [NB] keys, 8 bytes apart (low dword used here)
+    uint32_t* count = lds + L.count;
+    uint64_t* s8 = (uint64_t*)(lds + L.s8);                // [16R+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3)
+    uint32_t* work = lds + L.work;                         // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
 
     const int b = blockIdx.x;
     const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
@@ -97,76 +66,21 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
 
     STAMP(0);
     // ---- A: window, anchor, quadrant sums ------------------------------------------------
-    {
-        const int gx0 = bcol0 * 16 - d.sw, gy0 = r0 - d.sw;
-        const int rstep = T / d.pitch_dw;
-        const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
-        const int gx = gx0 + 4 * dw;
-        const bool colok = gx >= 0 && gx < d.pitch;
-        if (row0 < rstep) {
-            // batches of 4 independent loads, then 4 LDS stores: a plain load/store loop makes the
-            // compiler wait for every load before it issues the next one (one L2 latency per row)
-            const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
-            const long long sstep = (long long)rstep * d.pitch;
-            uint32_t* dst = win + row0 * d.pitch_dw + dw;
-            const int dstep = rstep * d.pitch_dw;
-            for (int row = row0; row < d.win_rows; row += 4 * rstep, src += 4 * sstep, dst += 4 * dstep) {
-                uint32_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int gy = gy0 + row + u * rstep;
-                    v[u] = 0;
-                    if (colok && row + u * rstep < d.win_rows && gy >= 0 && gy < d.H) v[u] = *(const uint32_t*)(src + u * sstep);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (row + u * rstep < d.win_rows) dst[u * dstep] = v[u];
-            }
-        }
-    }
+    stage_window(d, win, cur, bcol0, r0);
     uint32_t mine = 0, a01 = 0, a23 = 0;
     if (wave_ok) {
         const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
         anchor[wave * 64 + lane] = mine;
-        // quadrant sums: lane = (row, dword); xor 1 pairs the two dwords of a half row, xor 4/8/16
-        // sums the 8 rows of a half -> lanes 0, 2, 32, 34 hold the four 8x8 sums
-        uint32_t s = __builtin_amdgcn_sad_u8(mine, 0u, 0u);             // sum of this lane's 4 bytes
-        s += (uint32_t)__shfl_xor((int)s, 1, 64);
-        s += (uint32_t)__shfl_xor((int)s, 4, 64);
-        s += (uint32_t)__shfl_xor((int)s, 8, 64);
-        s += (uint32_t)__shfl_xor((int)s, 16, 64);
-        a01 = (uint32_t)__builtin_amdgcn_readlane((int)s, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 2) << 16);
-        a23 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 34) << 16);
+        anchor_quadrants(mine, &a01, &a23);
     }
     if (threadIdx.x == 0) *count = 0;
     STAMP(1);
     __syncthreads();
     STAMP(2);
 
-    // ---- A': 8x8 box sums of the window ---------------------------------------------------------
-    // Thread (column quad sq, row chunk ch) walks CH+7 window rows: per row two QSADs against a
-    // zero reference give the four horizontal 8-byte sums r8(row, 4sq .. 4sq+3) (packed u16); the
-    // vertical 8-row sum slides: S8(y) = S8(y-1) + r8(y+7) - r8(y-1), ring of 8 rows in registers.
-    {
-        typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-        constexpr int CH = 2 * R + 1;                      // 8 chunks cover NC + 8 = 16R + 8 rows
-        for (int it = threadIdx.x; it < 8 * XQ; it += T) {
-            const int ch = it / XQ, sq = it - ch * XQ;
-            const uint32_t* p = win + (ch * CH) * d.pitch_dw + sq;
-            u16x4 ring[8], sum = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int r = 0; r < CH + 7; ++r) {
-                const uint64_t w0 = *(const u64_a4*)(p + r * d.pitch_dw), w1 = *(const u64_a4*)(p + r * d.pitch_dw + 1);
-                const u16x4 h = __builtin_bit_cast(u16x4, __builtin_amdgcn_qsad_pk_u16_u8(
-                                    w1, 0u, __builtin_amdgcn_qsad_pk_u16_u8(w0, 0u, (uint64_t)0)));
-                if (r >= 8) sum -= ring[r & 7];
-                sum += h;
-                ring[r & 7] = h;
-                if (r >= 7) s8[(ch * CH + r - 7) * XQ + sq] = __builtin_bit_cast(uint64_t, sum);
-            }
-        }
-    }
+    // ---- A': 8x8 box sums of the window (bbme_sea_common.h) ------------------------------------
+    box_sums8<R>(d, win, s8);
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -234,7 +148,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
             packed = wave_sum_u32(packed);
             ub_key = min(((packed & 0xFFFFu) << 13) | (uint32_t)idx0, ((packed >> 16) << 13) | (uint32_t)idx1);
         }
-        if (lane == 0) best[wave] = ub_key;
+        if (lane == 0) best[2 * wave] = ub_key;
         // ---- D: surviving patches -> workgroup list
         const uint32_t ub = ub_key >> 13;
 #pragma unroll
@@ -260,7 +174,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
             uint32_t ent = 0;
             if (active) {
                 ent = work[e];
-                active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
+                active = (ent & 0xFFFFu) <= (best[2 * (ent >> 25)] >> 13);       // dropped by a tightened UB
             }
             // the quad is uniform in `active` (same entry), so the DPP exchange below is safe
             const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
@@ -316,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
                         key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
                     }
                 }
-                if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+                if (key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
             }
             __syncthreads();
         }
@@ -330,7 +244,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
             uint32_t ent = 0;
             if (active) {
                 ent = work[e];
-                active = (ent & 0xFFFFu) <= (best[ent >> 25] >> 13);       // dropped by a tightened UB
+                active = (ent & 0xFFFFu) <= (best[2 * (ent >> 25)] >> 13);       // dropped by a tightened UB
             }
             if (active) {
                 const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
@@ -369,7 +283,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
                         key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
                     }
                 }
-                if (key != 0xFFFFFFFFu) atomicMin(&best[w2], key);
+                if (key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
             }
             __syncthreads();
         }
@@ -378,25 +292,12 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     STAMP(7);
     // ---- F: result ------------------------------------------------------------------------------
     if (wave_ok && lane == 0) {
-        const int idx = (int)(best[wave] & 0x1FFF);
+        const int idx = (int)(best[2 * wave] & 0x1FFF);
         const int ci = idx / NC, ri = idx - ci * NC;
         int32_t* o = d.mf + (((long long)pair * d.nbr + brow) * d.nbc + bcol) * 2;
         o[0] = ci - d.sw;
         o[1] = ri - d.sw;
     }
-}
-
-int pick_pitch_sea(int need, int R)
-{
-    int best_p = need, best_c = 1 << 30;
-    for (int p = need; p < need + 33; ++p) {
-        int conflicts = 0, seen[32];
-        for (int i = 0; i < 32; ++i) seen[i] = 0;
-        for (int prow = 0; prow < 8; ++prow)
-            for (int q = 0; q < 4; ++q) conflicts += seen[((prow * R) * p + q * R) & 31]++;
-        if (conflicts < best_c) { best_c = conflicts; best_p = p; }
-    }
-    return best_p;
 }
 
 }  // namespace
@@ -427,41 +328,13 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
 #ifdef GME_SEA_STAMPS
     d.stamps = g_stamps;
 #endif
-    // Waves (= macroblocks) per workgroup.  More blocks share more of the staged window and of the
-    // box-sum pass, but LDS per workgroup grows; pick the count that keeps most waves resident per
-    // CU (160 KiB LDS, 32 waves), discounted by the idle waves of a ragged last workgroup.
-    auto lds_bytes = [&](int nb_, int* pitch_out, int* xq_out) {
-        const int xq = (4 * R + 4 * (nb_ - 1) + 2) | 1;                 // S8 quads per row, odd pitch
-        const int need_dw = (nb_ - 1) * 4 + 3 * R + (R - 1) + 5;        // base + k + 4 pairs of two dwords
-        const int pitch = pick_pitch_sea(need_dw > xq + 2 ? need_dw : xq + 2, R);
-        const size_t head = (size_t)(16 * R + 15) * pitch + (size_t)nb_ * 64 + nb_ + 1;
-        if (pitch_out) *pitch_out = pitch;
-        if (xq_out) *xq_out = xq;
-        return (((head + 1) & ~(size_t)1) + 2 * (size_t)(16 * R + 8) * xq + (size_t)nb_ * 64 * R) * 4;
-    };
-    int nb = 0;
-    double best_score = -1.0;
-    for (int cand = 1; cand <= 16 && cand <= nbc; ++cand) {
-        const size_t bytes = lds_bytes(cand, nullptr, nullptr);
-        if (bytes > 160 * 1024) break;
-        const int wgs = (int)((160 * 1024) / (bytes + 1024));           // allocation granularity slack
-        const int waves = wgs * cand > 32 ? 32 : wgs * cand;
-        const int per_row = (nbc + cand - 1) / cand;
-        const double score = waves * ((double)nbc / (per_row * cand)) + cand * 1e-3 + (nbc % cand == 0 ? 0.05 : 0.0);
-        if (score > best_score) { best_score = score; nb = cand; }
-    }
-    if (const char* e = getenv("GME_SEA_NB")) nb = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
-    if (nb > nbc) nb = nbc;
-    GME_REQUIRE(nb >= 1, GME_ERR_ARG, "search window too large for LDS");
-    d.nb = nb;
-    d.wg_per_row = (nbc + nb - 1) / nb;
+    size_t lds = 0;
+    GME_REQUIRE(plan(R, nbc, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
     d.wg_per_pair = d.wg_per_row * nbr;
-    d.win_rows = 16 * R + 15;
-    const size_t lds = lds_bytes(nb, &d.pitch_dw, &d.xq);
-    GME_REQUIRE(lds <= 160 * 1024, GME_ERR_ARG, "search window too large for LDS");
+    d.sqbox = nullptr; d.sqbox_stride = 0;
     const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
     GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
-    const dim3 grid((unsigned)groups), block(64 * nb);
+    const dim3 grid((unsigned)groups), block(64 * d.nb);
     const bool e4 = getenv("GME_SEA_E4") != nullptr;           // A/B switch for phase E (4 lanes per patch)
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)

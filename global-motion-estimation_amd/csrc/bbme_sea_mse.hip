@@ -1,0 +1,264 @@
+// Exhaustive MSE search, bs = 16, with exact successive elimination -- same answer as
+// k_exh_dot16 (bbme_fast.hip) / bbme.py:105-179 with pnorm 1, a fraction of the work.
+//
+// Bound.  For each 8x8 quadrant q, (sum(A_q) - sum(B_q))^2 <= 64 * SSD_q (Cauchy-Schwarz on the 64
+// pixel differences), hence  LBx = sum_q dS_q^2 <= 64 * SSD.  With a real candidate's SSD as UB,
+// a candidate with LBx > 64 * UB has SSD > UB >= min and can neither win nor tie.  Bounds travel
+// as 16-bit values floor(LBx / 2^14) against floor(64 * UB / 2^14) = UB >> 8; comparing floors only
+// ever keeps more candidates, never fewer.
+//
+// Same phases as k_exh_sea16 (bbme_sea.hip); what differs:
+//   B  dS_q by v_pk_sub_i16 on the packed quadrant sums, squares summed by v_dot2_i32_i16;
+//   C  UB from two cooperative SSDs (sum a^2 + sum b^2 - 2 sum ab with v_dot4_u32_u8 per lane);
+//   E  a listed patch costs 16*R*16 v_dot4_u32_u8 (three v_alignbyte copies per window dword) for
+//      sum(A.B); sum(B^2) comes from the per-frame 16x16 box table of squares (k_sqbox16_*),
+//      sum(A^2) from phase A; 37-bit keys (ssd << 13 | scan index) merged with 64-bit LDS atomicMin.
+#include "bbme_sea_common.h"
+
+namespace {
+
+using namespace sea;
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned long long u64min_(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+
+template <int R>
+__global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const int NB = d.nb, T = blockDim.x;
+    const int NC = 2 * d.sw + 16, XQ = d.xq;
+    const Layout L = make_layout(R, NB, d.win_rows, d.pitch_dw, XQ);
+    uint32_t* win = lds + L.win;
+    uint32_t* anchor = lds + L.anchor;
+    unsigned long long* best = (unsigned long long*)(lds + L.best);     // [NB] ssd << 13 | scan index
+    uint32_t* count = lds + L.count;
+    uint32_t* a2s = lds + L.a2;                                         // [NB] sum of squares of each anchor
+    uint64_t* s8 = (uint64_t*)(lds + L.s8);
+    uint32_t* work = lds + L.work;
+
+    const int b = blockIdx.x;
+    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    if (pair >= d.pairs) return;
+    const int wg = (b >> 3) % d.wg_per_pair;
+    const int brow = wg / d.wg_per_row;
+    const int bcol0 = (wg - brow * d.wg_per_row) * NB;
+    const int r0 = brow * 16;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bcol = bcol0 + wave;
+    const bool wave_ok = bcol < d.nbc;
+    const int c0 = bcol * 16;
+    const int prow = lane >> 2, q = lane & 3;
+
+    // ---- A
+    stage_window(d, win, cur, bcol0, r0);
+    uint32_t mine = 0, a01 = 0, a23 = 0, mine2 = 0;
+    if (wave_ok) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        anchor[wave * 64 + lane] = mine;
+        anchor_quadrants(mine, &a01, &a23);
+        mine2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
+        const uint32_t a2 = wave_sum_u32(mine2);
+        if (lane == 0) a2s[wave] = a2;
+    }
+    if (threadIdx.x == 0) *count = 0;
+    __syncthreads();
+
+    // ---- A'
+    box_sums8<R>(d, win, s8);
+    __syncthreads();
+
+    // ---- B
+    const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
+    if (wave_ok) {
+        const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
+        uint32_t pkey[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
+        const bool interior = lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ri = prow * R + i;
+            if (!interior && (ri < lo_r || ri > hi_r)) continue;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int ci0 = q * 4 * R + 4 * k;
+                if (!interior && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
+                const uint64_t* sp = s8 + ri * XQ + wave * 4 + q * R + k;
+                const uint64_t ta = sp[0], tb = sp[2], ba = sp[8 * XQ], bb = sp[8 * XQ + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!interior && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t top = __builtin_amdgcn_perm((uint32_t)(tb >> (32 * (e >> 1))), (uint32_t)(ta >> (32 * (e >> 1))), sel);
+                    const uint32_t bot = __builtin_amdgcn_perm((uint32_t)(bb >> (32 * (e >> 1))), (uint32_t)(ba >> (32 * (e >> 1))), sel);
+                    const s16x2 dt = __builtin_bit_cast(s16x2, top) - __builtin_bit_cast(s16x2, a01);   // |d| <= 16320
+                    const s16x2 db = __builtin_bit_cast(s16x2, bot) - __builtin_bit_cast(s16x2, a23);
+                    const uint32_t lbx = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
+                    pkey[k] = min(pkey[k], ((lbx >> 14) << 13) + (uint32_t)((4 * k + e) * R + i));
+                }
+            }
+        }
+        uint32_t patch_lb[R], lb_key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 13;
+            lb_key = min(lb_key, pkey[k]);
+        }
+        if (lb_key != 0xFFFFFFFFu) lb_key += (uint32_t)lane << 7;
+        // ---- C
+        lb_key = wave_min_u32(lb_key);
+        unsigned long long ub_key = ~0ull;
+        {
+            const int bl = (lb_key >> 7) & 63, loc = lb_key & 127;
+            const int ce = loc / R, li = loc - ce * R;
+            const int idx1 = ((bl & 3) * 4 * R + ce) * NC + (bl >> 2) * R + li;
+            const int idx0 = d.sw * NC + d.sw;
+            const int arow = lane >> 2, aj = lane & 3;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int idx = which ? idx1 : idx0;
+                const int ci = idx / NC, ri = idx - ci * NC;
+                const int byte = wave * 16 + ci + 4 * aj;
+                const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
+                const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
+                const uint32_t part = mine2 + __builtin_amdgcn_udot4(v, v, 0u, false) - 2u * __builtin_amdgcn_udot4(v, mine, 0u, false);
+                const uint32_t ssd = wave_sum_u32(part);
+                ub_key = u64min_(ub_key, ((unsigned long long)ssd << 13) | (unsigned)idx);
+            }
+        }
+        if (lane == 0) best[wave] = ub_key;
+        // ---- D
+        const uint32_t ub16 = (uint32_t)(ub_key >> 21);                // (ssd >> 8) = floor(64 * ssd / 2^14)
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (patch_lb[k] <= ub16) {
+                const uint32_t slot = atomicAdd(count, 1u);
+                work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];
+            }
+    }
+    __syncthreads();
+
+    // ---- E
+    const int n = (int)*count;
+    const uint32_t* tab = d.sqbox + (long long)pair * d.sqbox_stride;
+    for (int base = 0; base < n; base += T) {
+        const int e = base + threadIdx.x;
+        bool active = e < n;
+        uint32_t ent = 0;
+        if (active) {
+            ent = work[e];
+            active = (ent & 0xFFFFu) <= (uint32_t)(best[ent >> 25] >> 21);
+        }
+        if (active) {
+            const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+            const int prow2 = l2 >> 2, q2 = l2 & 3;
+            const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+            const uint32_t* an = anchor + w2 * 64;
+            uint32_t acc[R][4];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = 0;
+#pragma unroll
+            for (int t = 0; t < R + 15; ++t) {
+                uint32_t w[5];
+#pragma unroll
+                for (int s = 0; s < 5; ++s) w[s] = lrow[t * d.pitch_dw + s];
+                uint32_t sh[4][4];                         // sh[j][e4] = bytes 4j+e4 .. 4j+e4+3 of the patch row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sh[j][0] = w[j];
+#pragma unroll
+                    for (int e4 = 1; e4 < 4; ++e4) sh[j][e4] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)e4);
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int a = t - i;
+                    if (a < 0 || a > 15) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t av = an[a * 4 + j];
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = __builtin_amdgcn_udot4(sh[j][e4], av, acc[i][e4], false);
+                    }
+                }
+                // keep the rows' dot products in program order (see k_exh_dot16)
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) asm volatile("" : "+v"(acc[i][e4]));
+            }
+            const int c02 = (bcol0 + w2) * 16;
+            const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+            const uint32_t a2 = a2s[w2];
+            unsigned long long key = ~0ull;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int ci = q2 * 4 * R + 4 * k2 + e4;
+                if (ci < lo_c || ci > hi_c) continue;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ri = prow2 * R + i;
+                    if (ri < lo_r || ri > hi_r) continue;
+                    const uint32_t b2 = tab[(long long)(r0 - d.sw + ri) * d.pitch + (c02 - d.sw + ci)];
+                    const uint32_t cost = a2 + b2 - 2u * acc[i][e4];
+                    key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)(ci * NC + ri));
+                }
+            }
+            if (key != ~0ull) atomicMin(&best[w2], key);
+        }
+        __syncthreads();
+    }
+
+    // ---- F
+    if (wave_ok && lane == 0) {
+        const int idx = (int)(best[wave] & 0x1FFF);
+        const int ci = idx / NC, ri = idx - ci * NC;
+        int32_t* o = d.mf + (((long long)pair * d.nbr + brow) * d.nbc + bcol) * 2;
+        o[0] = ci - d.sw;
+        o[1] = ri - d.sw;
+    }
+}
+
+}  // namespace
+
+int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
+{
+    *handled = false;
+    if (job.procedure != GME_SEARCH_EXHAUSTIVE || job.bs != 16 || job.pnorm != GME_NORM_MSE) return GME_OK;
+    if (job.sqbox_cur == nullptr || job.sw < 0 || job.sw % 4 != 0) return GME_OK;
+    if (getenv("GME_FORCE_GENERIC") || getenv("GME_EXH_BRUTE")) return GME_OK;
+    const int NC = 2 * job.sw + 16, R = (NC + 15) / 16;
+    if (R < 1 || R > 5 || NC * NC > 8192) return GME_OK;
+    const int nbr = job.H / 16, nbc = job.W / 16;
+    if (nbr == 0 || nbc == 0) return GME_OK;
+    SeaDev d;
+    d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
+    d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
+    d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
+    d.sqbox = job.sqbox_cur; d.sqbox_stride = job.sqbox_stride;
+#ifdef GME_SEA_STAMPS
+    d.stamps = nullptr;
+#endif
+    size_t lds = 0;
+    if (!plan(R, nbc, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
+    d.wg_per_pair = d.wg_per_row * nbr;
+    const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
+    GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
+    const dim3 grid((unsigned)groups), block(64 * d.nb);
+    switch (R) {
+    case 1: hipLaunchKernelGGL(k_exh_sea16_mse<1>, grid, block, lds, ctx->stream, d); break;
+    case 2: hipLaunchKernelGGL(k_exh_sea16_mse<2>, grid, block, lds, ctx->stream, d); break;
+    case 3: hipLaunchKernelGGL(k_exh_sea16_mse<3>, grid, block, lds, ctx->stream, d); break;
+    case 4: hipLaunchKernelGGL(k_exh_sea16_mse<4>, grid, block, lds, ctx->stream, d); break;
+    default: hipLaunchKernelGGL(k_exh_sea16_mse<5>, grid, block, lds, ctx->stream, d); break;
+    }
+    GME_HIP_TRY(hipGetLastError());
+    *handled = true;
+    return GME_OK;
+}

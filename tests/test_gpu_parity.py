@@ -484,13 +484,14 @@ def test_successive_elimination_equals_brute_force(golden, mods, monkeypatch):
     cases = [(g3["in_race_prev"], g3["in_race_cur"], 16), (g3["in_pan240_prev"], g3["in_pan240_cur"], 8),
              (synth.frame(5, 0, 270, 480), synth.frame(5, 3, 270, 480), 32), (flat, flat, 16),
              (quant, np.roll(quant, (3, -5), (0, 1)), 12), (synth.frame(6, 0, 50, 70), synth.frame(6, 1, 50, 70), 4)]
-    sea = [bbme.get_motion_field(p, c, 16, sw, 0, 0) for p, c, sw in cases]
-    monkeypatch.setenv("GME_EXH_BRUTE", "1")
-    for (p, c, sw), want in zip(cases, sea):
-        assert np.array_equal(bbme.get_motion_field(p, c, 16, sw, 0, 0), want), sw
+    sea = {pn: [bbme.get_motion_field(p, c, 16, sw, 0, pn) for p, c, sw in cases] for pn in (0, 1)}
+    monkeypatch.setenv("GME_EXH_BRUTE", "1")           # k_exh_qsad16 / k_exh_dot16 instead
     co = c_oracle()
-    for (p, c, sw), want in list(zip(cases, sea))[2:]:
-        assert np.array_equal(co.bbme(p, c, 16, sw, 0, 0), want), sw
+    for pn in (0, 1):
+        for (p, c, sw), want in zip(cases, sea[pn]):
+            assert np.array_equal(bbme.get_motion_field(p, c, 16, sw, 0, pn), want), (pn, sw)
+        for (p, c, sw), want in list(zip(cases, sea[pn]))[2:]:
+            assert np.array_equal(co.bbme(p, c, 16, sw, 0, pn), want), (pn, sw)
 
 
 @pytest.mark.parametrize("pnorm", [0, 1])
