@@ -318,30 +318,56 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
 }
 
 // 16x16 box sums of squares, two separable passes over one plane stack.
+// Pass 1: thread -> four horizontal 16-byte sums of squares at x .. x+3 (x % 4 == 0): five aligned
+// dwords, three v_alignbyte copies of each, sixteen v_dot4(b, b).  Pass 2: thread -> the same four
+// columns, sliding down a chunk of rows: S(y+1) = S(y) + r(y+16) - r(y).
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+
 __global__ void __launch_bounds__(256) k_sqbox16_rows(const uint8_t* src, long long src_stride, int H, int W, int pitch,
                                                       uint32_t* dst, long long dst_stride)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x > W - 16 || y >= H) return;
-    const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y * pitch + x;
-    uint32_t s = 0;
+    const uint32_t* p = (const uint32_t*)(src + (long long)blockIdx.z * src_stride + (long long)y * pitch + x);
+    uint32_t w[5];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += (uint32_t)p[k] * p[k];
-    dst[(long long)blockIdx.z * dst_stride + (long long)y * pitch + x] = s;
+    for (int j = 0; j < 5; ++j) w[j] = (x + 4 * j < pitch) ? p[j] : 0u;     // last dword may lie past the pitch
+    u32x4_v out;
+    uint32_t r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = e == 0 ? w[j] : __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)e);
+            r[e] = __builtin_amdgcn_udot4(v, v, r[e], false);
+        }
+    }
+    out.x = r[0]; out.y = r[1]; out.z = r[2]; out.w = r[3];          // columns beyond W-16 are never read
+    *(u32x4_v*)(dst + (long long)blockIdx.z * dst_stride + (long long)y * pitch + x) = out;
 }
+
+constexpr int SQ_CHUNK = 32;
 
 __global__ void __launch_bounds__(256) k_sqbox16_cols(const uint32_t* rows, uint32_t* dst, long long stride, int H, int W,
                                                       int pitch)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x > W - 16 || y > H - 16) return;
-    const uint32_t* p = rows + (long long)blockIdx.z * stride + (long long)y * pitch + x;
-    uint32_t s = 0;
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SQ_CHUNK;
+    if (x > W - 16 || y0 > H - 16) return;
+    const uint32_t* p = rows + (long long)blockIdx.z * stride + (long long)y0 * pitch + x;
+    uint32_t* o = dst + (long long)blockIdx.z * stride + (long long)y0 * pitch + x;
+    u32x4_v s = { 0, 0, 0, 0 };
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += p[(long long)k * pitch];
-    dst[(long long)blockIdx.z * stride + (long long)y * pitch + x] = s;
+    for (int k = 0; k < 16; ++k) s += *(const u32x4_v*)(p + (long long)k * pitch);
+    *(u32x4_v*)o = s;
+    const int last = min(SQ_CHUNK - 1, H - 16 - y0);
+    for (int k = 1; k <= last; ++k) {
+        s += *(const u32x4_v*)(p + (long long)(k + 15) * pitch);
+        s -= *(const u32x4_v*)(p + (long long)(k - 1) * pitch);
+        *(u32x4_v*)(o + (long long)k * pitch) = s;
+    }
 }
 
 // LDS row pitch (in dwords) that keeps the per-row ds_read2_b32 of a half-wave on
@@ -431,10 +457,12 @@ int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int c
     if (count == 0 || H < 16 || W < 16) return GME_OK;
     for (int first = 0; first < count; first += 32768) {
         const int n = count - first < 32768 ? count - first : 32768;
-        const dim3 grid((W - 15 + 63) / 64, (H + 3) / 4, n);
-        hipLaunchKernelGGL(k_sqbox16_rows, grid, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W,
+        const int xq = (W - 16) / 4 + 1;                            // column quads that hold a valid position
+        const dim3 g1((xq + 63) / 64, (H + 3) / 4, n);
+        const dim3 g2((xq + 63) / 64, ((H - 15 + SQ_CHUNK - 1) / SQ_CHUNK + 3) / 4, n);
+        hipLaunchKernelGGL(k_sqbox16_rows, g1, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W,
                            pitch, tmp + first * stride, stride);
-        hipLaunchKernelGGL(k_sqbox16_cols, grid, dim3(256), 0, ctx->stream, tmp + first * stride, out + first * stride,
+        hipLaunchKernelGGL(k_sqbox16_cols, g2, dim3(256), 0, ctx->stream, tmp + first * stride, out + first * stride,
                            stride, H, W, pitch);
     }
     GME_HIP_TRY(hipGetLastError());
