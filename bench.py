@@ -268,8 +268,8 @@ def main():
                 if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                     vals[f[1]] = float(f[-1].split("=")[1])
             if len(vals) == 2:
-                out["roofline"]["traffic"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e9
-                out["roofline"]["traffic_unit"] = "GB per launch, from profiles/r01_final_exh720_pmc_summary.txt"
+                out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+                out["roofline"]["traffic_unit"] = "bytes per launch, from profiles/r01_final_exh720_pmc_summary.txt"
         if proc == 0:
             ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
             # brute-force-equivalent rate: the exhaustive search's nominal byte abs-diffs per second.

@@ -208,6 +208,24 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
     } while (0)
 
+    // Diamond rounds: every lane knows its own pattern offset, so the candidate position is two
+    // vector adds + clamps instead of an 8-way select of wave-uniform arrays; the bounding box of
+    // the (clamped) pattern is scalar arithmetic.
+#define EVALP(n, RRV, CCV, RMIN, RMAX, CMIN, CMAX, COST)                                              \
+    do {                                                                                             \
+        bool lds_ok_ = true;                                                                         \
+        if (!(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 &&         \
+              (CMAX) <= wc0 + WIN_SPAN)) {                                                           \
+            wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                                  \
+            wc0 = ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3;                            \
+            stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
+            have_win = true;                                                                         \
+        }                                                                                            \
+        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, wr0, wc0, RRV, CCV, grp < (n), lrow);  \
+        (void)lds_ok_;                                                                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
+    } while (0)
+
     int out0 = 0, out1 = 0;
     bool overrun = false;
     const int cap = 2 * (H + W) + 64;
@@ -224,15 +242,24 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
             EVAL8(1, cr, cc, ok, cost);
             centre_cost = cost[0];
         }
+        // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns
+        int my_dr = 0, my_dc = 0, my_sr = 0, my_sc = 0;
+        const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (grp == k) { my_dr = ldr[k]; my_dc = ldc[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (grp == k) { my_sr = sdr[k]; my_sc = sdc[k]; }
         int it = 0;
         for (;;) {
             // candidate 0 of the pattern is the clamped centre itself
             unsigned best = centre_cost;
             int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
-            int cr[8], cc[8]; bool ok[8]; unsigned cost[8];
+            int cr[8], cc[8]; unsigned cost[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { cr[k] = clamp_ref(pr + ldr[k], maxr); cc[k] = clamp_ref(pc + ldc[k], maxc); ok[k] = true; }
-            EVAL8(8, cr, cc, ok, cost);
+            for (int k = 0; k < 8; ++k) { cr[k] = clamp_ref(pr + ldr[k], maxr); cc[k] = clamp_ref(pc + ldc[k], maxc); }
+            const int rrv = clamp_ref(pr + my_dr, maxr), ccv = clamp_ref(pc + my_dc, maxc);
+            EVALP(8, rrv, ccv, clamp_ref(pr - 2, maxr), clamp_ref(pr + 2, maxr), clamp_ref(pc - 2, maxc),
+                  clamp_ref(pc + 2, maxc), cost);
 #pragma unroll
             for (int k = 0; k < 8; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
             const bool done = (br == pr && bc == pc);
@@ -242,13 +269,14 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         }
         // small pattern, offsets applied swapped (bbme.py:518-521): (0,0),(1,0),(0,1),(-1,0),(0,-1) -> row += o[1], col += o[0]
         {
-            const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
             unsigned best = centre_cost;
             int br = pr, bc = pc;
-            int cr[4], cc[4]; bool ok[4]; unsigned cost[4];
+            int cr[4], cc[4]; unsigned cost[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { cr[k] = clamp_ref(pr + sdr[k], maxr); cc[k] = clamp_ref(pc + sdc[k], maxc); ok[k] = true; }
-            EVAL8(4, cr, cc, ok, cost);
+            for (int k = 0; k < 4; ++k) { cr[k] = clamp_ref(pr + sdr[k], maxr); cc[k] = clamp_ref(pc + sdc[k], maxc); }
+            const int rrv = clamp_ref(pr + my_sr, maxr), ccv = clamp_ref(pc + my_sc, maxc);
+            EVALP(4, rrv, ccv, clamp_ref(pr - 1, maxr), clamp_ref(pr + 1, maxr), clamp_ref(pc - 1, maxc),
+                  clamp_ref(pc + 1, maxc), cost);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
             out1 = br - r0; out0 = bc - c0;
@@ -314,6 +342,7 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         out1 = br - r0; out0 = bc - c0;
     }
 #undef EVAL8
+#undef EVALP
     if (lane == 0) {
         if (overrun) atomicExch(d.status, 1);
         int32_t* o = d.mf + gid * 2;
