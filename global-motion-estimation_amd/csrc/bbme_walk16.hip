@@ -156,10 +156,14 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
 {
     __shared__ uint32_t win_all[4][WIN_ROWS * WIN_PITCH];
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long gid = (long long)blockIdx.x * 4 + wave_in_wg;
     const int nblk = d.nbr * d.nbc;
-    if (gid >= (long long)nblk * d.pairs) return;              // wave-uniform
-    const int pair = (int)(gid / nblk), blk = (int)(gid % nblk);
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b serves pair
+    // (b/8/WPP)*8 + b%8 -- all blocks of a frame pair walk through one XCD's L2
+    const int wpp = (nblk + 3) >> 2;
+    const int pair = ((int)blockIdx.x / 8 / wpp) * 8 + ((int)blockIdx.x & 7);
+    const int blk = (((int)blockIdx.x >> 3) % wpp) * 4 + wave_in_wg;
+    if (pair >= d.pairs || blk >= nblk) return;                // wave-uniform
+    const long long gid = (long long)pair * nblk + blk;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, lrow = (lane & 7) * 2;           // group = candidate slot, lane = 2 block rows
@@ -423,7 +427,10 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf; d.status = ctx->status;
     const long long total = (long long)nbr * nbc * job.pairs;
     if (job.bs == 16) {
-        const unsigned grid = (unsigned)((total + 3) / 4);
+        const long long wpp = ((long long)nbr * nbc + 3) / 4;
+        const long long groups = (long long)((job.pairs + 7) / 8) * 8 * wpp;
+        GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
+        const unsigned grid = (unsigned)groups;
         if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
         else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
