@@ -284,6 +284,22 @@ def main():
             rows, ref_mf = cb.pop("rows_checked"), cb.pop("mf")
             cb["matches_gpu"] = bool(all(np.array_equal(ref_mf[r], mv[r]) for r in rows))
             out["cpu_baseline"] = cb
+            # BASELINE.md §3 "optimised CPU": the integer C oracle (gcc -O3, one core) on the same
+            # pair, so the GPU figure is not only measured against interpreter overhead
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tests"))
+                from helpers import c_oracle
+                import synth
+                p0, p1 = synth.frame(seed, 0, H, W), synth.frame(seed, 1, H, W)
+                co = c_oracle()
+                t_c = time.perf_counter()
+                mf_c = co.bbme(p0, p1, bs, sw, proc, pnorm)
+                t_c = time.perf_counter() - t_c
+                out["cpu_baseline_c"] = {"value": 1.0 / t_c, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                         "sample": "oracle/gme_oracle.c (integer C, gcc -O3) on the whole pair t=0,1 in %.2f s" % t_c,
+                                         "matches_gpu": bool(np.array_equal(mf_c, mv))}
+            except Exception as e:      # the C oracle is optional test infrastructure
+                out["cpu_baseline_c"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

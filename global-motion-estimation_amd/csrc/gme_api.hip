@@ -66,7 +66,6 @@ extern "C" void gme_destroy(gme_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->status) hipFree(ctx->status);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -148,23 +147,6 @@ int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out)
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
-    return GME_OK;
-}
-
-int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out)
-{
-    if (bytes > ctx->pinned_bytes) {
-        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->pinned) hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
-        if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) {
-            gme_set_error("out of pinned host memory (%zu bytes)", bytes);
-            return GME_ERR_NOMEM;
-        }
-        ctx->pinned_bytes = bytes;
-    }
-    *out = ctx->pinned;
     return GME_OK;
 }
 

@@ -49,14 +49,10 @@ struct gme_ctx {
     // growable device scratch for the single-pair convenience calls
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    // pinned host staging for small read-backs
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
     int* status = nullptr;        // device word set by kernels whose safety guards trip
 };
 
 int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);
-int ctx_pinned(gme_ctx* ctx, size_t bytes, void** out);
 int plane_alloc(gme_ctx* ctx, Plane* p, int count, int H, int W);
 void plane_free(Plane* p);
 
