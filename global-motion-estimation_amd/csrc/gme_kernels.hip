@@ -21,57 +21,76 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// Each thread produces 4 horizontally adjacent output pixels.  Interior threads read, per
-// source row, the 16 aligned bytes [2x-4, 2x+12) that hold the 11 taps 2x-2 .. 2x+8 (one
-// dword-aligned 16-byte load instead of 20 byte loads); border threads take the reflecting path.
+// Each thread produces 4 horizontally adjacent output pixels.  k_pyrdown covers the interior quads
+// (x in [4, x_end)): per source row the 16 aligned bytes [2x-4, 2x+12) hold the 11 taps
+// 2x-2 .. 2x+8 (one dword-aligned 16-byte load instead of 20 byte loads).  The quads that touch the
+// left/right border need BORDER_REFLECT_101 per tap; they run in their own small launch
+// (k_pyrdown_edge) so that no interior wave has to execute the slow path as well.
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ int pyr_interior_end(int sW, int dW)
+{
+    // largest multiple of 4, x_end, such that every quad x in [4, x_end) has 2x+12 <= sW and x+4 <= dW
+    int e = min((sW - 12) / 2 + 4, dW) & ~3;
+    return e < 4 ? 4 : e;
+}
 
 __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long src_stride, int sH, int sW,
                                                   int spitch, uint8_t* dst, long long dst_stride, int dH,
                                                   int dW, int dpitch)
 {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int x = 4 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dW || y >= dH) return;
+    if (x >= pyr_interior_end(sW, dW) || y >= dH) return;
     const uint8_t* s = src + (long long)blockIdx.z * src_stride;
     uint8_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y * dpitch + x;
     const int k[5] = { 1, 4, 6, 4, 1 };
     int acc[4] = { 0, 0, 0, 0 };
-    const bool interior = x >= 4 && 2 * x + 12 <= sW && x + 4 <= dW;
-    if (interior) {
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-            const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch + 2 * x - 4;
-            const u32x4_a4 v = *(const u32x4_a4*)row;
-            const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
-            int t[16];
+    for (int dy = 0; dy < 5; ++dy) {
+        const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch + 2 * x - 4;
+        const u32x4_a4 v = *(const u32x4_a4*)row;
+        const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+        int t[16];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) t[b] = (wds[b >> 2] >> (8 * (b & 3))) & 0xFF;
+        for (int b = 0; b < 16; ++b) t[b] = (wds[b >> 2] >> (8 * (b & 3))) & 0xFF;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {                  // taps of output p start at byte 2 + 2p
-                const int h = t[2 + 2 * p] + 4 * t[3 + 2 * p] + 6 * t[4 + 2 * p] + 4 * t[5 + 2 * p] + t[6 + 2 * p];
-                acc[p] += k[dy] * h;
-            }
+        for (int p = 0; p < 4; ++p) {                      // taps of output p start at byte 2 + 2p
+            const int h = t[2 + 2 * p] + 4 * t[3 + 2 * p] + 6 * t[4 + 2 * p] + 4 * t[5 + 2 * p] + t[6 + 2 * p];
+            acc[p] += k[dy] * h;
         }
-        *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) |
-                        ((uint32_t)((acc[2] + 128) >> 8) << 16) | ((uint32_t)((acc[3] + 128) >> 8) << 24);
-        return;
     }
-    for (int p = 0; p < 4 && x + p < dW; ++p) {
-        int cx[5];
+    *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) |
+                    ((uint32_t)((acc[2] + 128) >> 8) << 16) | ((uint32_t)((acc[3] + 128) >> 8) << 24);
+}
+
+// border pixels: x in [0, 4) and [x_end, dW); one thread per pixel
+__global__ void __launch_bounds__(256) k_pyrdown_edge(const uint8_t* src, long long src_stride, int sH, int sW,
+                                                       int spitch, uint8_t* dst, long long dst_stride, int dH,
+                                                       int dW, int dpitch)
+{
+    const int x_end = pyr_interior_end(sW, dW);
+    const int n_left = min(4, dW), n_right = max(0, dW - x_end);
+    const int per_row = n_left + n_right;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int y = id / per_row, e = id - y * per_row;      // a wave covers 64 / per_row rows: few cache lines per load
+    if (y >= dH) return;
+    const int x = e < n_left ? e : x_end + (e - n_left);
+    const uint8_t* s = src + (long long)blockIdx.z * src_stride;
+    const int k[5] = { 1, 4, 6, 4, 1 };
+    int cx[5];
 #pragma unroll
-        for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * (x + p) + d - 2, sW);
-        int a = 0;
+    for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * x + d - 2, sW);
+    int a = 0;
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-            const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch;
-            int h = 0;
+    for (int dy = 0; dy < 5; ++dy) {
+        const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch;
+        int h = 0;
 #pragma unroll
-            for (int d = 0; d < 5; ++d) h += k[d] * row[cx[d]];
-            a += k[dy] * h;
-        }
-        o[p] = (uint8_t)((a + 128) >> 8);
+        for (int d = 0; d < 5; ++d) h += k[d] * row[cx[d]];
+        a += k[dy] * h;
     }
+    dst[(long long)blockIdx.z * dst_stride + (long long)y * dpitch + x] = (uint8_t)((a + 128) >> 8);
 }
 
 // ---------------------------------------------------------------------------
@@ -377,8 +396,18 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
 {
     GME_REQUIRE(dst.H == (src.H + 1) / 2 && dst.W == (src.W + 1) / 2 && dst.count == src.count, GME_ERR_ARG,
                 "pyrdown: destination shape mismatch");
-    const dim3 grid((dst.W + 255) / 256, (dst.H + 3) / 4, src.count);
-    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
+    // host copy of pyr_interior_end
+    int x_end = (((src.W - 12) / 2 + 4) < dst.W ? ((src.W - 12) / 2 + 4) : dst.W) & ~3;
+    if (x_end < 4) x_end = 4;
+    const int interior_quads = (x_end - 4) / 4;
+    if (interior_quads > 0) {
+        const dim3 grid((interior_quads + 63) / 64, (dst.H + 3) / 4, src.count);
+        hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
+                           src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
+    }
+    const int per_row = (dst.W < 4 ? dst.W : 4) + (dst.W - x_end > 0 ? dst.W - x_end : 0);
+    const dim3 egrid((dst.H * per_row + 255) / 256, 1, src.count);
+    hipLaunchKernelGGL(k_pyrdown_edge, egrid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
                        src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
