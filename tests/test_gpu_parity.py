@@ -546,3 +546,33 @@ def test_exhaustive_bs16_random_geometries(mods):
         for pn in (0, 1):
             got = bbme.get_motion_field(p, c, 16, sw, 0, pn)
             assert np.array_equal(got, co.bbme(p, c, 16, sw, 0, pn)), (trial, H, W, sw, pn)
+
+
+def test_walk_searches_random_geometries(mods):
+    """Randomised sweep of the specialised walk kernels (bs = 16 with its LDS window cache, bs = 2
+    dense) incl. long walks that leave and re-centre the cached window, vs the C oracle."""
+    _, bbme, _, _ = mods
+    co = c_oracle()
+    rng = np.random.default_rng(77)
+    for trial in range(30):
+        H, W = int(rng.integers(17, 200)), int(rng.integers(17, 300))
+        sw = int(rng.choice([2, 3, 7, 12, 16, 25, 40]))
+        kind = trial % 3
+        if kind == 0:       # smooth ramp + texture: walks run far (dozens of steps)
+            yy, xx = np.mgrid[0:H + 120, 0:W + 120]
+            base = ((yy * 3 + xx * 2) // 4 % 256).astype(np.uint8) ^ (rng.integers(0, 4, (H + 120, W + 120)).astype(np.uint8))
+            dy, dx = int(rng.integers(-50, 51)), int(rng.integers(-50, 51))
+            p, c = base[60:60 + H, 60:60 + W], base[60 + dy:60 + dy + H, 60 + dx:60 + dx + W]
+        elif kind == 1:
+            p, c = rng.integers(0, 256, (H, W), dtype=np.uint8), rng.integers(0, 256, (H, W), dtype=np.uint8)
+        else:
+            p = (rng.integers(0, 2, (H, W)) * 200).astype(np.uint8)
+            c = np.roll(p, (int(rng.integers(-6, 7)), int(rng.integers(-6, 7))), (0, 1))
+        p, c = np.ascontiguousarray(p), np.ascontiguousarray(c)
+        for bs in (16, 2):
+            if bs == 2 and trial % 5:
+                continue
+            for sp in (1, 2, 3):
+                for pn in (0, 1):
+                    got = bbme.get_motion_field(p, c, bs, sw, sp, pn)
+                    assert np.array_equal(got, co.bbme(p, c, bs, sw, sp, pn)), (trial, H, W, bs, sw, sp, pn)
