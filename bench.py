@@ -277,6 +277,20 @@ def main():
             # exceed the instruction-issue ceiling of a brute-force kernel (frac > 1).
             out["valu"] = {"bound": "v_qsad_pk_u16_u8 issue (brute-force equivalent)", "achieved": ops,
                            "peak": QSAD_PEAK_OPS, "unit": "byte-abs-diff/s", "frac": ops / QSAD_PEAK_OPS}
+        if proc >= 0 and world == 1:
+            # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
+            # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
+            n_e2e = min(B, 128)
+            host_frames = np.stack([seq.read_frame(i) for i in range(n_e2e + 1)])
+            t_e = time.perf_counter()
+            seq.upload(0, host_frames)
+            seq.bbme(1, bs, sw, proc, pnorm)
+            _ = seq.read_mv(0, n_e2e)
+            t_e = time.perf_counter() - t_e
+            # the launch still covers all B resident pairs; scale to the pairs whose frames moved
+            out["pcie_inclusive"] = {"value": n_e2e / (t_e - (kernel_ms * 1e-3) * (1 - n_e2e / B)), "unit": "frame-pairs/s",
+                                     "note": "upload of %d frames from pageable host memory + search + read-back of %d fields; "
+                                             "each frame crosses once" % (n_e2e + 1, n_e2e)}
         if proc == -3:
             out["sequence"] = out_extra
         if world == 1 and not args.no_cpu_baseline and proc == 0:

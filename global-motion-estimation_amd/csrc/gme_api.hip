@@ -374,9 +374,15 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
     GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
                 "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
     const Plane& p = s->level[2];
-    for (int i = 0; i < count; ++i)
-        GME_HIP_TRY(hipMemcpy2DAsync(p.at(first + i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
+    if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
+        // planes and host frames are both back to back: one 2-D copy of count*H rows
+        GME_HIP_TRY(hipMemcpy2DAsync(p.at(first), p.pitch, frames, row_stride, s->W, (size_t)s->H * count,
                                      hipMemcpyHostToDevice, s->ctx->stream));
+    } else {
+        for (int i = 0; i < count; ++i)
+            GME_HIP_TRY(hipMemcpy2DAsync(p.at(first + i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W,
+                                         s->H, hipMemcpyHostToDevice, s->ctx->stream));
+    }
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // the host buffer may be reused on return
