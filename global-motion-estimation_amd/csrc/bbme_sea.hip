@@ -29,10 +29,49 @@ namespace {
 using namespace sea;
 
 #ifdef GME_SEA_STAMPS
-#define STAMP(i) do { if (lane == 0) d.stamps[((long long)blockIdx.x * NB + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (lane == 0) d.stamps[((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NB + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
+
+
+// B: lower bounds of the 4R x R candidates of one lane (candidate rows prow*R + i, columns
+// q*4R + 4k + e).  GUARD = false is the branch-free body for blocks whose whole window is inside
+// the frame (84 % of them at 720x480, sw = 16); GUARD = true skips candidates outside [lo, hi].
+template <int R, bool GUARD>
+__device__ __forceinline__ void lower_bounds(const uint64_t* sp0, int XQ, int prow, int q, uint32_t a01, uint32_t a23,
+                                             int lo_r, int hi_r, int lo_c, int hi_c, uint32_t (&pkey)[R])
+{
+#pragma unroll
+    for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
+    const uint64_t* top = sp0;
+    const uint64_t* bot = sp0 + 8 * XQ;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int ri = prow * R + i;
+        if (!GUARD || (ri >= lo_r && ri <= hi_r)) {
+            uint64_t t[R + 2], b[R + 2];                   // quads k and k + 2 for k < R: R + 2 distinct ones
+#pragma unroll
+            for (int k = 0; k < R + 2; ++k) { t[k] = top[k]; b[k] = bot[k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int ci0 = q * 4 * R + 4 * k;
+                if (GUARD && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (GUARD && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t tp = __builtin_amdgcn_perm((uint32_t)(t[k + 2] >> (32 * (e >> 1))), (uint32_t)(t[k] >> (32 * (e >> 1))), sel);
+                    const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b[k + 2] >> (32 * (e >> 1))), (uint32_t)(b[k] >> (32 * (e >> 1))), sel);
+                    const uint32_t lb = __builtin_amdgcn_sad_u16(tp, a01, __builtin_amdgcn_sad_u16(bt, a23, 0u));
+                    pkey[k] = min(pkey[k], (lb << 13) + (uint32_t)((4 * k + e) * R + i));
+                }
+            }
+        }
+        top += XQ;
+        bot += XQ;
+    }
+}
 
 template <int R, bool E4>
 __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
@@ -48,12 +87,8 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     uint64_t* s8 = (uint64_t*)(lds + L.s8);                // [16R+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3)
     uint32_t* work = lds + L.work;                         // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
 
-    const int b = blockIdx.x;
-    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
-    if (pair >= d.pairs) return;                           // whole workgroup
-    const int wg = (b >> 3) % d.wg_per_pair;
-    const int brow = wg / d.wg_per_row;
-    const int bcol0 = (wg - brow * d.wg_per_row) * NB;
+    int pair, brow, bcol0;
+    if (!locate(d, &pair, &brow, &bcol0)) return;          // whole workgroup
     const int r0 = brow * 16;
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
 
@@ -87,6 +122,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
 
     // ---- B: lower bounds of the wave's own block --------------------------------------------
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
+    const bool rows_inside = NC == 16 * R && lo_r == 0 && hi_r == NC - 1;   // and no padding candidates
     uint32_t patch_lb[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) patch_lb[k] = 0xFFFFFFFFu;
@@ -96,30 +132,11 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
         // per patch k: min over its candidates of (LB << 13) + local, local = (4k+e)*R + i (any
         // consistent index will do here: the bound only has to name one good candidate)
         uint32_t pkey[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
-        const bool interior = lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1;   // wave-uniform
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int ri = prow * R + i;
-            if (!interior && (ri < lo_r || ri > hi_r)) continue;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int ci0 = q * 4 * R + 4 * k;
-                if (!interior && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
-                const uint64_t* sp = s8 + ri * XQ + wave * 4 + q * R + k;
-                const uint64_t ta = sp[0], tb = sp[2], ba = sp[8 * XQ], bb = sp[8 * XQ + 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!interior && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
-                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-                    const uint32_t top = __builtin_amdgcn_perm((uint32_t)(tb >> (32 * (e >> 1))), (uint32_t)(ta >> (32 * (e >> 1))), sel);
-                    const uint32_t bot = __builtin_amdgcn_perm((uint32_t)(bb >> (32 * (e >> 1))), (uint32_t)(ba >> (32 * (e >> 1))), sel);
-                    const uint32_t lb = __builtin_amdgcn_sad_u16(top, a01, __builtin_amdgcn_sad_u16(bot, a23, 0u));
-                    pkey[k] = min(pkey[k], (lb << 13) + (uint32_t)((4 * k + e) * R + i));
-                }
-            }
-        }
+        const uint64_t* sp0 = s8 + (prow * R) * XQ + wave * 4 + q * R;
+        if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
+            lower_bounds<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
+        else
+            lower_bounds<R, true>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
         uint32_t lb_key = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -217,17 +234,30 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
             if (active && sub == 0) {
                 const int c02 = (bcol0 + w2) * 16;
                 const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
                 uint32_t key = 0xFFFFFFFFu;
+                if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+                    // whole window inside the frame: keys relative to the patch's first candidate, base added once
     #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int ci = q2 * 4 * R + 4 * k2 + e4;
-                    if (ci < lo_c || ci > hi_c) continue;
+                    for (int e4 = 0; e4 < 4; ++e4)
     #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        const int ri = prow2 * R + i;
-                        if (ri < lo_r || ri > hi_r) continue;
-                        const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
-                        key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                        for (int i = 0; i < R; ++i) {
+                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                            key = min(key, (sad << 13) + (uint32_t)(e4 * NC + i));
+                        }
+                    key += (uint32_t)(ci0 * NC + ri0);
+                } else {
+    #pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int ci = ci0 + e4;
+                        if (ci < lo_c || ci > hi_c) continue;
+    #pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const int ri = ri0 + i;
+                            if (ri < lo_r || ri > hi_r) continue;
+                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                            key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                        }
                     }
                 }
                 if (key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
@@ -270,17 +300,30 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
                 }
                 const int c02 = (bcol0 + w2) * 16;
                 const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
                 uint32_t key = 0xFFFFFFFFu;
+                if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+                    // whole window inside the frame: keys relative to the patch's first candidate, base added once
     #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int ci = q2 * 4 * R + 4 * k2 + e4;
-                    if (ci < lo_c || ci > hi_c) continue;
+                    for (int e4 = 0; e4 < 4; ++e4)
     #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        const int ri = prow2 * R + i;
-                        if (ri < lo_r || ri > hi_r) continue;
-                        const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
-                        key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                        for (int i = 0; i < R; ++i) {
+                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                            key = min(key, (sad << 13) + (uint32_t)(e4 * NC + i));
+                        }
+                    key += (uint32_t)(ci0 * NC + ri0);
+                } else {
+    #pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int ci = ci0 + e4;
+                        if (ci < lo_c || ci > hi_c) continue;
+    #pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const int ri = ri0 + i;
+                            if (ri < lo_r || ri > hi_r) continue;
+                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
+                            key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+                        }
                     }
                 }
                 if (key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
@@ -332,9 +375,9 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     GME_REQUIRE(plan(R, nbc, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
     d.wg_per_pair = d.wg_per_row * nbr;
     d.sqbox = nullptr; d.sqbox_stride = 0;
-    const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
-    GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
-    const dim3 grid((unsigned)groups), block(64 * d.nb);
+    dim3 grid;
+    GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+    const dim3 block(64 * d.nb);
     const bool e4 = getenv("GME_SEA_E4") != nullptr;           // A/B switch for phase E (4 lanes per patch)
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)

@@ -14,6 +14,9 @@ struct SeaDev {
     int pairs, H, W, pitch, sw;
     int nbr, nbc, nb, wg_per_row, wg_per_pair;
     int pitch_dw, win_rows;
+    int rstep;                    // staging: window rows covered by one sweep of the workgroup (T / pitch_dw)
+    uint32_t magic_pitch;         // n / pitch_dw == (n * magic_pitch) >> 20 for n < 4096 (div_small)
+    uint32_t magic_xq;            // same for n / xq
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
     const uint32_t* sqbox;        // MSE only: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
@@ -25,18 +28,65 @@ struct SeaDev {
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
 
+// Wave-wide reductions without LDS traffic: four DPP steps leave every lane with the result of its
+// 16-lane row (xor 1, xor 2 inside quads, then the two mirrors), v_readlane + SALU combine the four rows.
+#define SEA_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, false))
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
+    v = min(v, SEA_DPP(v, 0xB1));                          // quad_perm [1,0,3,2]
+    v = min(v, SEA_DPP(v, 0x4E));                          // quad_perm [2,3,0,1]
+    v = min(v, SEA_DPP(v, 0x141));                         // row_half_mirror
+    v = min(v, SEA_DPP(v, 0x140));                         // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
+    v += SEA_DPP(v, 0xB1);
+    v += SEA_DPP(v, 0x4E);
+    v += SEA_DPP(v, 0x141);
+    v += SEA_DPP(v, 0x140);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// n / dv for n < 4096 and dv < 256 without the 20-odd instructions of an emulated division:
+// magic = 2^20 / dv + 1 overshoots the reciprocal by < 2^-20, so the product is off by < 2^-8 < 1 / dv.
+inline uint32_t div_magic(int dv) { return (1u << 20) / (uint32_t)dv + 1u; }
+__device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(__umul24((uint32_t)n, magic) >> 20); }
+
+// Workgroup -> (pair, block row, first block column).  Grid = (8 * wg_per_row, nbr, ceil(pairs / 8)):
+// workgroups go to the 8 XCDs round robin in x-fastest order, so the low 3 bits of blockIdx.x pick
+// the pair inside a group of 8 and all tiles of one pair land on one XCD (its L2 holds the pair).
+__device__ __forceinline__ bool locate(const SeaDev& d, int* pair, int* brow, int* bcol0)
+{
+#ifdef SEA_GRID1D
+    const int b = blockIdx.x;
+    *pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    const int wg = (b >> 3) % d.wg_per_pair;
+    *brow = wg / d.wg_per_row;
+    *bcol0 = (wg - *brow * d.wg_per_row) * d.nb;
+#else
+    *pair = (int)blockIdx.z * 8 + (int)(blockIdx.x & 7);
+    *brow = (int)blockIdx.y;
+    *bcol0 = (int)(blockIdx.x >> 3) * d.nb;
+#endif
+    return *pair < d.pairs;
+}
+
+inline bool grid_for(const SeaDev& d, dim3* grid)
+{
+    const long long gz = ((long long)d.pairs + 7) / 8;
+#ifdef SEA_GRID1D
+    if (gz * 8 * d.wg_per_pair >= (1ll << 31)) return false;
+    *grid = dim3((unsigned)(gz * 8 * d.wg_per_pair));
+#else
+    if (gz > 65535 || d.nbr > 65535) return false;
+    *grid = dim3((unsigned)(8 * d.wg_per_row), (unsigned)d.nbr, (unsigned)gz);
+#endif
+    return true;
 }
 
 // LDS carve-up shared by both kernels (dword offsets); `best` holds NB 64-bit slots so the MSE
@@ -64,16 +114,15 @@ __host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int p
 // batches of four so that their latencies overlap.
 __device__ __forceinline__ void stage_window(const SeaDev& d, uint32_t* win, const uint8_t* cur, int bcol0, int r0)
 {
-    const int T = blockDim.x;
     const int gx0 = bcol0 * 16 - d.sw, gy0 = r0 - d.sw;
-    const int rstep = T / d.pitch_dw;
-    const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
+    const int rstep = d.rstep;
+    const int row0 = div_small((int)threadIdx.x, d.magic_pitch), dw = (int)threadIdx.x - row0 * d.pitch_dw;
     const int gx = gx0 + 4 * dw;
     const bool colok = gx >= 0 && gx < d.pitch;
     if (row0 < rstep) {
         const uint8_t* src = cur + (long long)(gy0 + row0) * d.pitch + gx;
         const long long sstep = (long long)rstep * d.pitch;
-        uint32_t* dst = win + row0 * d.pitch_dw + dw;
+        uint32_t* dst = win + threadIdx.x;                     // == row0 * pitch_dw + dw
         const int dstep = rstep * d.pitch_dw;
         for (int row = row0; row < d.win_rows; row += 4 * rstep, src += 4 * sstep, dst += 4 * dstep) {
             uint32_t v[4];
@@ -101,33 +150,43 @@ __device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, 
     constexpr int CH = 2 * R + 1;                      // 8 chunks cover 16R + 8 rows
     const int XQ = d.xq;
     for (int it = threadIdx.x; it < 8 * XQ; it += blockDim.x) {
-        const int ch = it / XQ, sq = it - ch * XQ;
-        const uint32_t* p = win + (ch * CH) * d.pitch_dw + sq;
+        const int ch = div_small(it, d.magic_xq), sq = it - ch * XQ;
+        int pi = (ch * CH) * d.pitch_dw + sq, oi = (ch * CH) * XQ + sq;     // running offsets: adds, no r * pitch multiplies
         u16x4 ring[8], sum = { 0, 0, 0, 0 };
 #pragma unroll
         for (int r = 0; r < CH + 7; ++r) {
-            const uint64_t w0 = *(const u64_a4*)(p + r * d.pitch_dw), w1 = *(const u64_a4*)(p + r * d.pitch_dw + 1);
+            const uint64_t w0 = *(const u64_a4*)(win + pi), w1 = *(const u64_a4*)(win + pi + 1);
+            pi += d.pitch_dw;
+            asm volatile("" : "+v"(pi));
             const u16x4 h = __builtin_bit_cast(u16x4, __builtin_amdgcn_qsad_pk_u16_u8(
                                 w1, 0u, __builtin_amdgcn_qsad_pk_u16_u8(w0, 0u, (uint64_t)0)));
             if (r >= 8) sum -= ring[r & 7];
             sum += h;
             ring[r & 7] = h;
-            if (r >= 7) s8[(ch * CH + r - 7) * XQ + sq] = __builtin_bit_cast(uint64_t, sum);
+            if (r >= 7) {
+                s8[oi] = __builtin_bit_cast(uint64_t, sum);
+                oi += XQ;
+                asm volatile("" : "+v"(oi));
+            }
         }
     }
 }
 
-// quadrant sums of the anchor held one dword per lane (lane = row * 4 + dword): xor 1 pairs the
-// two dwords of a half row, xor 4/8/16 sums the 8 rows of a half -> lanes 0, 2, 32, 34.
+// quadrant sums of the anchor held one dword per lane (lane = row * 4 + dword): the quad swap pairs
+// the two dwords of a half row, row_ror 4 and 8 add the four rows inside a 16-lane DPP row, the two
+// DPP rows of each half are added on the scalar side.
 __device__ __forceinline__ void anchor_quadrants(uint32_t mine, uint32_t* a01, uint32_t* a23)
 {
     uint32_t s = __builtin_amdgcn_sad_u8(mine, 0u, 0u);
-    s += (uint32_t)__shfl_xor((int)s, 1, 64);
-    s += (uint32_t)__shfl_xor((int)s, 4, 64);
-    s += (uint32_t)__shfl_xor((int)s, 8, 64);
-    s += (uint32_t)__shfl_xor((int)s, 16, 64);
-    *a01 = (uint32_t)__builtin_amdgcn_readlane((int)s, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 2) << 16);
-    *a23 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32) | ((uint32_t)__builtin_amdgcn_readlane((int)s, 34) << 16);
+    s += SEA_DPP(s, 0xB1);                                 // quad_perm [1,0,3,2]
+    s += SEA_DPP(s, 0x124);                                // row_ror 4
+    s += SEA_DPP(s, 0x128);                                // row_ror 8
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)s, 0) + (uint32_t)__builtin_amdgcn_readlane((int)s, 16);
+    const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)s, 2) + (uint32_t)__builtin_amdgcn_readlane((int)s, 18);
+    const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)s, 32) + (uint32_t)__builtin_amdgcn_readlane((int)s, 48);
+    const uint32_t q3 = (uint32_t)__builtin_amdgcn_readlane((int)s, 34) + (uint32_t)__builtin_amdgcn_readlane((int)s, 50);
+    *a01 = q0 | (q1 << 16);
+    *a23 = q2 | (q3 << 16);
 }
 
 inline int pick_pitch(int need, int R)
@@ -177,7 +236,10 @@ inline bool plan(int R, int nbc, SeaDev* d, size_t* lds_bytes)
     d->wg_per_row = (nbc + nb - 1) / nb;
     d->win_rows = 16 * R + 15;
     *lds_bytes = bytes_for(nb, &d->pitch_dw, &d->xq);
-    return *lds_bytes <= 160 * 1024;
+    d->rstep = 64 * nb / d->pitch_dw;
+    d->magic_pitch = div_magic(d->pitch_dw);
+    d->magic_xq = div_magic(d->xq);
+    return *lds_bytes <= 160 * 1024 && d->pitch_dw < 256 && d->xq < 256;
 }
 
 }  // namespace sea

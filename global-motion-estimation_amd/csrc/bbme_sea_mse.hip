@@ -23,6 +23,45 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned long long u64min_(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
+
+// B: as lower_bounds() of bbme_sea.hip, with the squared bound floor(sum_q dS_q^2 / 2^14).
+template <int R, bool GUARD>
+__device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, int prow, int q, uint32_t a01, uint32_t a23,
+                                                 int lo_r, int hi_r, int lo_c, int hi_c, uint32_t (&pkey)[R])
+{
+#pragma unroll
+    for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
+    const uint64_t* top = sp0;
+    const uint64_t* bot = sp0 + 8 * XQ;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int ri = prow * R + i;
+        if (!GUARD || (ri >= lo_r && ri <= hi_r)) {
+            uint64_t t[R + 2], b[R + 2];
+#pragma unroll
+            for (int k = 0; k < R + 2; ++k) { t[k] = top[k]; b[k] = bot[k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int ci0 = q * 4 * R + 4 * k;
+                if (GUARD && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (GUARD && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t tp = __builtin_amdgcn_perm((uint32_t)(t[k + 2] >> (32 * (e >> 1))), (uint32_t)(t[k] >> (32 * (e >> 1))), sel);
+                    const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b[k + 2] >> (32 * (e >> 1))), (uint32_t)(b[k] >> (32 * (e >> 1))), sel);
+                    const s16x2 dt = __builtin_bit_cast(s16x2, tp) - __builtin_bit_cast(s16x2, a01);   // |d| <= 16320
+                    const s16x2 db = __builtin_bit_cast(s16x2, bt) - __builtin_bit_cast(s16x2, a23);
+                    const uint32_t lbx = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
+                    pkey[k] = min(pkey[k], ((lbx >> 14) << 13) + (uint32_t)((4 * k + e) * R + i));
+                }
+            }
+        }
+        top += XQ;
+        bot += XQ;
+    }
+}
+
 template <int R>
 __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 {
@@ -38,12 +77,8 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     uint64_t* s8 = (uint64_t*)(lds + L.s8);
     uint32_t* work = lds + L.work;
 
-    const int b = blockIdx.x;
-    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
-    if (pair >= d.pairs) return;
-    const int wg = (b >> 3) % d.wg_per_pair;
-    const int brow = wg / d.wg_per_row;
-    const int bcol0 = (wg - brow * d.wg_per_row) * NB;
+    int pair, brow, bcol0;
+    if (!locate(d, &pair, &brow, &bcol0)) return;
     const int r0 = brow * 16;
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -74,35 +109,15 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 
     // ---- B
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
+    const bool rows_inside = NC == 16 * R && lo_r == 0 && hi_r == NC - 1;   // and no padding candidates
     if (wave_ok) {
         const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
         uint32_t pkey[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
-        const bool interior = lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int ri = prow * R + i;
-            if (!interior && (ri < lo_r || ri > hi_r)) continue;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int ci0 = q * 4 * R + 4 * k;
-                if (!interior && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
-                const uint64_t* sp = s8 + ri * XQ + wave * 4 + q * R + k;
-                const uint64_t ta = sp[0], tb = sp[2], ba = sp[8 * XQ], bb = sp[8 * XQ + 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!interior && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
-                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-                    const uint32_t top = __builtin_amdgcn_perm((uint32_t)(tb >> (32 * (e >> 1))), (uint32_t)(ta >> (32 * (e >> 1))), sel);
-                    const uint32_t bot = __builtin_amdgcn_perm((uint32_t)(bb >> (32 * (e >> 1))), (uint32_t)(ba >> (32 * (e >> 1))), sel);
-                    const s16x2 dt = __builtin_bit_cast(s16x2, top) - __builtin_bit_cast(s16x2, a01);   // |d| <= 16320
-                    const s16x2 db = __builtin_bit_cast(s16x2, bot) - __builtin_bit_cast(s16x2, a23);
-                    const uint32_t lbx = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
-                    pkey[k] = min(pkey[k], ((lbx >> 14) << 13) + (uint32_t)((4 * k + e) * R + i));
-                }
-            }
-        }
+        const uint64_t* sp0 = s8 + (prow * R) * XQ + wave * 4 + q * R;
+        if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
+            lower_bounds_mse<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
+        else
+            lower_bounds_mse<R, true>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
         uint32_t patch_lb[R], lb_key = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -197,17 +212,33 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
             const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
             const uint32_t a2 = a2s[w2];
             unsigned long long key = ~0ull;
+            const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
+            const uint32_t* trow = tab + (long long)(r0 - d.sw + ri0) * d.pitch + (c02 - d.sw + ci0);
+            if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+                uint32_t b2[R][4];                             // all table reads in flight before the first use
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int ci = q2 * 4 * R + 4 * k2 + e4;
-                if (ci < lo_c || ci > hi_c) continue;
+                for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int ri = prow2 * R + i;
-                    if (ri < lo_r || ri > hi_r) continue;
-                    const uint32_t b2 = tab[(long long)(r0 - d.sw + ri) * d.pitch + (c02 - d.sw + ci)];
-                    const uint32_t cost = a2 + b2 - 2u * acc[i][e4];
-                    key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)(ci * NC + ri));
+                    for (int e4 = 0; e4 < 4; ++e4) b2[i][e4] = trow[(long long)i * d.pitch + e4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const uint32_t cost = a2 + b2[i][e4] - 2u * acc[i][e4];
+                        key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)((ci0 + e4) * NC + ri0 + i));
+                    }
+            } else {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int ci = ci0 + e4;
+                    if (ci < lo_c || ci > hi_c) continue;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int ri = ri0 + i;
+                        if (ri < lo_r || ri > hi_r) continue;
+                        const uint32_t cost = a2 + trow[(long long)i * d.pitch + e4] - 2u * acc[i][e4];
+                        key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)(ci * NC + ri));
+                    }
                 }
             }
             if (key != ~0ull) atomicMin(&best[w2], key);
@@ -248,9 +279,9 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     size_t lds = 0;
     if (!plan(R, nbc, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
     d.wg_per_pair = d.wg_per_row * nbr;
-    const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
-    GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
-    const dim3 grid((unsigned)groups), block(64 * d.nb);
+    dim3 grid;
+    GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+    const dim3 block(64 * d.nb);
     switch (R) {
     case 1: hipLaunchKernelGGL(k_exh_sea16_mse<1>, grid, block, lds, ctx->stream, d); break;
     case 2: hipLaunchKernelGGL(k_exh_sea16_mse<2>, grid, block, lds, ctx->stream, d); break;

@@ -1,0 +1,17 @@
+# usage: bash tools/ab.sh "<lib names under tools/microbench without libgme_ prefix>" "<bench configs>" [rounds]
+# Same-box A/B of library builds (device-to-device variance is ~12 %, so only compare inside one call).
+set -e
+cd /root/repo
+L=global-motion-estimation_amd/lib/libgme_hip.so
+cp $L /tmp/keep.so
+for r in $(seq 1 ${3:-2}); do
+for v in $1; do
+  cp tools/microbench/libgme_$v.so $L
+  for c in $2; do
+    echo -n "$v $c "; timeout -k 10 200 python3 bench.py --config $c --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(round(d['value']))"
+  done
+done
+done
+cp /tmp/keep.so $L
