@@ -73,49 +73,31 @@ __device__ __forceinline__ void lower_bounds(const uint64_t* sp0, int XQ, int pr
     }
 }
 
+// Phases A' .. F of one tile.  On entry the window and the anchors are staged, *count == 0 and the
+// workgroup has passed a barrier; there is no barrier after F.
 template <int R, bool E4>
-__global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
+__device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+                                            uint32_t mine, uint32_t a01, uint32_t a23, int tid)
 {
-    extern __shared__ uint32_t lds[];
     const int NB = d.nb, T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
-    const Layout L = make_layout(R, NB, d.win_rows, d.pitch_dw, XQ);
     uint32_t* win = lds + L.win;                           // [win_rows][pitch_dw]
     uint32_t* anchor = lds + L.anchor;                     // [NB][64]
     uint32_t* best = lds + L.best;                         // [NB] keys, 8 bytes apart (low dword used here)
     uint32_t* count = lds + L.count;
     uint64_t* s8 = (uint64_t*)(lds + L.s8);                // [16R+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3)
     uint32_t* work = lds + L.work;                         // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
-
-    int pair, brow, bcol0;
-    if (!locate(d, &pair, &brow, &bcol0)) return;          // whole workgroup
     const int r0 = brow * 16;
-    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int bcol = bcol0 + wave;
     const bool wave_ok = bcol < d.nbc;                     // ragged last workgroup of a block row
     const int c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
-
-    STAMP(0);
-    // ---- A: window, anchor, quadrant sums ------------------------------------------------
-    stage_window(d, win, cur, bcol0, r0);
-    uint32_t mine = 0, a01 = 0, a23 = 0;
-    if (wave_ok) {
-        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
-        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        anchor[wave * 64 + lane] = mine;
-        anchor_quadrants(mine, &a01, &a23);
-    }
-    if (threadIdx.x == 0) *count = 0;
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
+    (void)NB; (void)T;
 
     // ---- A': 8x8 box sums of the window (bbme_sea_common.h) ------------------------------------
-    box_sums8<R>(d, win, s8);
+    box_sums8<R>(d, win, s8, tid);
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -186,7 +168,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
         const int n = (int)*count;
         const int sub = lane & 3;
         for (int base = 0; base < n; base += T / 4) {
-            const int e = base + (threadIdx.x >> 2);
+            const int e = base + (tid >> 2);
             bool active = e < n;
             uint32_t ent = 0;
             if (active) {
@@ -269,7 +251,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
         // ---- E: evaluate the listed patches, one per lane ---------------------------------------
         const int n = (int)*count;
         for (int base = 0; base < n; base += T) {
-            const int e = base + threadIdx.x;
+            const int e = base + tid;
             bool active = e < n;
             uint32_t ent = 0;
             if (active) {
@@ -343,6 +325,127 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     }
 }
 
+template <int R, bool E4>
+__global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
+    int pair, brow, bcol0;
+    if (!locate(d, &pair, &brow, &bcol0)) return;          // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int NB = d.nb;
+    (void)NB;
+
+    STAMP(0);
+    // ---- A: window, anchor, quadrant sums ------------------------------------------------
+    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    uint32_t mine = 0, a01 = 0, a23 = 0;
+    if (bcol0 + wave < d.nbc) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        lds[L.anchor + wave * 64 + lane] = mine;
+        anchor_quadrants(mine, &a01, &a23);
+    }
+    if (threadIdx.x == 0) lds[L.count] = 0;
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+    tile_phases<R, E4>(d, lds, L, pair, brow, bcol0, mine, a01, a23, (int)threadIdx.x);
+}
+
+// Persistent form: G workgroups (two per CU) walk the tiles of "their" XCD's pairs; the window and
+// anchor of the next tile are fetched into registers while the current one is searched, so the
+// HBM/L2 latency of phase A overlaps phases A' .. F instead of idling the workgroup's 16 waves.
+template <int R, int NV>
+__global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
+    const int xcd = blockIdx.x & 7, gx = gridDim.x >> 3;
+    const int npairs_x = (d.pairs - xcd + 7) >> 3;          // pairs with pair % 8 == xcd
+    const int ntiles = npairs_x * d.wg_per_pair;
+    int tile = blockIdx.x >> 3;
+    if (tile >= ntiles) return;
+
+    // Everything derived from the thread index is recomputed per tile from an opaque copy (the empty
+    // asm): hoisted out of the tile loop those values cost more registers than the 64 that eight
+    // waves per SIMD allow, and a spill reload (vmcnt) would wait for the prefetch it sits behind.
+    uint32_t wv[NV], an_next = 0;
+    int pair = 0, brow = 0, bcol0 = 0;
+    auto fetch = [&](int t) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int row0 = div_small(tid, d.magic_pitch), dw = tid - row0 * d.pitch_dw;
+        const int lp = (int)(((unsigned long long)(unsigned)t * d.magic_wpp) >> 40);
+        const int wg = t - lp * d.wg_per_pair;
+        brow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
+        bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+        pair = lp * 8 + xcd;
+        const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+        const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = brow * 16 - d.sw + row0;
+        const bool colok = row0 < d.rstep && gx0 >= 0 && gx0 < d.pitch;
+        const uint8_t* src = cur + (long long)gy0 * d.pitch + gx0;
+        const long long sstep = (long long)d.rstep * d.pitch;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int gy = gy0 + u * d.rstep;
+            wv[u] = 0;
+            if (colok && row0 + u * d.rstep < d.win_rows && gy >= 0 && gy < d.H) wv[u] = *(const uint32_t*)(src + u * sstep);
+        }
+        an_next = 0;
+        if (bcol0 + wave < d.nbc) {
+            const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+            an_next = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        }
+    };
+    fetch(tile);
+    // Dynamic schedule (d.tile_ctr): after its first tile a workgroup draws tile numbers gx + n from its
+    // XCD's counter.  Thread 0 asks one tile ahead, so the atomic's round trip is waited for together
+    // with the prefetched window (same vmcnt), never on its own.
+    uint32_t* ctr = d.tile_ctr ? d.tile_ctr + 16 * xcd : nullptr;
+    uint32_t drawn = 0;
+    if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);   // not atomicAdd: LLVM would aggregate it over the wave and wait for the result at once
+    for (;;) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        // registers -> LDS
+        {
+            const int row0 = div_small(tid, d.magic_pitch);
+            if (row0 < d.rstep) {
+                uint32_t* dst = lds + L.win + tid;
+                const int dstep = d.rstep * d.pitch_dw;
+#pragma unroll
+                for (int u = 0; u < NV; ++u)
+                    if (row0 + u * d.rstep < d.win_rows) dst[u * dstep] = wv[u];
+            }
+        }
+        const int pair_c = pair, brow_c = brow, bcol0_c = bcol0;
+        const uint32_t mine = an_next;
+        uint32_t a01 = 0, a23 = 0;
+        if (bcol0_c + wave < d.nbc) {
+            lds[L.anchor + wave * 64 + lane] = mine;
+            anchor_quadrants(mine, &a01, &a23);
+        }
+        if (tid == 0) {
+            lds[L.count] = 0;
+            if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
+        }
+        __syncthreads();
+        tile = ctr ? (int)lds[L.count + 1] : tile + gx;
+        const bool more = tile < ntiles;                   // workgroup-uniform
+        if (more) {
+            fetch(tile);
+            if (ctr && tid == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);   // not atomicAdd: LLVM would aggregate it over the wave and wait for the result at once
+        }
+        tile_phases<R, false>(d, lds, L, pair_c, brow_c, bcol0_c, mine, a01, a23, tid);
+        if (!more) break;
+        __syncthreads();                                   // everyone is done with this tile's LDS
+    }
+}
+
 }  // namespace
 
 bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm)
@@ -365,6 +468,7 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const int nbr = job.H / 16, nbc = job.W / 16;
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
+    d.tile_ctr = nullptr;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
@@ -375,9 +479,44 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     GME_REQUIRE(plan(R, nbc, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
     d.wg_per_pair = d.wg_per_row * nbr;
     d.sqbox = nullptr; d.sqbox_stride = 0;
+    d.magic_wpp = div_magic40(d.wg_per_pair);
+    d.magic_wpr = div_magic40(d.wg_per_row);
+    const dim3 block(64 * d.nb);
+    const long long tiles_x = (((long long)job.pairs + 7) / 8) * d.wg_per_pair;      // per XCD
+    const int nv = (d.win_rows + d.rstep - 1) / d.rstep;
+    // Persistent form by default when every resident workgroup gets several tiles; GME_SEA_PERSIST = 0
+    // forces the one-tile-per-workgroup kernel, 1 / 2 force the persistent one (static / dynamic schedule).
+    const char* pmode = getenv("GME_SEA_PERSIST");
+    const int pm = pmode ? atoi(pmode) : -1;
+    int per_cu = (int)((160 * 1024) / (lds + 1024));           // resident workgroups per CU: LDS, 32 wave slots
+    if (per_cu * d.nb > 32) per_cu = 32 / d.nb;
+    if (per_cu < 1) per_cu = 1;
+    long long g = (long long)per_cu * ctx->prop.multiProcessorCount / 8;            // per XCD
+    const bool can_persist = tiles_x < (1ll << 21) && d.wg_per_pair < (1 << 18) && nv <= 16 && g >= 1;
+    const bool persist = can_persist && (pm > 0 || (pm < 0 && tiles_x >= 4 * g));
+    if (persist) {
+        if (g > tiles_x) g = tiles_x;
+        const dim3 grid((unsigned)(8 * g));
+        d.tile_ctr = nullptr;
+        if (pm != 1) {
+            d.tile_ctr = (uint32_t*)ctx->status + 64;
+            GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+        }
+#define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p<RR, NVV>), grid, block, lds, ctx->stream, d)
+#define SEA_LAUNCH_PN(RR) do { if (nv <= 6) SEA_LAUNCH_P(RR, 6); else if (nv <= 8) SEA_LAUNCH_P(RR, 8); \
+                               else if (nv <= 12) SEA_LAUNCH_P(RR, 12); else SEA_LAUNCH_P(RR, 16); } while (0)
+        switch (R) {
+        case 1: SEA_LAUNCH_PN(1); break;
+        case 2: SEA_LAUNCH_PN(2); break;
+        case 3: SEA_LAUNCH_PN(3); break;
+        case 4: SEA_LAUNCH_PN(4); break;
+        default: SEA_LAUNCH_PN(5); break;
+        }
+#undef SEA_LAUNCH_PN
+#undef SEA_LAUNCH_P
+    } else {
     dim3 grid;
     GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
-    const dim3 block(64 * d.nb);
     const bool e4 = getenv("GME_SEA_E4") != nullptr;           // A/B switch for phase E (4 lanes per patch)
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
@@ -389,6 +528,7 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     default: SEA_LAUNCH(5); break;
     }
 #undef SEA_LAUNCH
+    }
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
     return GME_OK;

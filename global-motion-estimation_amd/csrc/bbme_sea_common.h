@@ -17,6 +17,9 @@ struct SeaDev {
     int rstep;                    // staging: window rows covered by one sweep of the workgroup (T / pitch_dw)
     uint32_t magic_pitch;         // n / pitch_dw == (n * magic_pitch) >> 20 for n < 4096 (div_small)
     uint32_t magic_xq;            // same for n / xq
+    unsigned long long magic_wpp; // persistent kernel: n / wg_per_pair == (n * magic_wpp) >> 40 for n < 2^21
+    unsigned long long magic_wpr; // same for n / wg_per_row
+    uint32_t* tile_ctr;           // persistent kernel, dynamic schedule: one counter per XCD, 16 words apart (or null)
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
     const uint32_t* sqbox;        // MSE only: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
@@ -55,6 +58,8 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 // n / dv for n < 4096 and dv < 256 without the 20-odd instructions of an emulated division:
 // magic = 2^20 / dv + 1 overshoots the reciprocal by < 2^-20, so the product is off by < 2^-8 < 1 / dv.
 inline uint32_t div_magic(int dv) { return (1u << 20) / (uint32_t)dv + 1u; }
+// same idea for n < 2^21, dv < 2^18: (n * magic40) >> 40, error < 2^21 / 2^40 < 1 / dv
+inline unsigned long long div_magic40(int dv) { return (1ull << 40) / (unsigned long long)dv + 1ull; }
 __device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(__umul24((uint32_t)n, magic) >> 20); }
 
 // Workgroup -> (pair, block row, first block column).  Grid = (8 * wg_per_row, nbr, ceil(pairs / 8)):
@@ -144,12 +149,12 @@ __device__ __forceinline__ void stage_window(const SeaDev& d, uint32_t* win, con
 // r8(row, 4sq .. 4sq+3) (packed u16); the vertical 8-row sum slides with a ring of 8 rows in
 // registers: S8(y) = S8(y-1) + r8(y+7) - r8(y-1).  s8[y][sq] = packed S8(y, 4sq .. 4sq+3).
 template <int R>
-__device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, uint64_t* s8)
+__device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
 {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     constexpr int CH = 2 * R + 1;                      // 8 chunks cover 16R + 8 rows
     const int XQ = d.xq;
-    for (int it = threadIdx.x; it < 8 * XQ; it += blockDim.x) {
+    for (int it = tid; it < 8 * XQ; it += blockDim.x) {
         const int ch = div_small(it, d.magic_xq), sq = it - ch * XQ;
         int pi = (ch * CH) * d.pitch_dw + sq, oi = (ch * CH) * XQ + sq;     // running offsets: adds, no r * pitch multiplies
         u16x4 ring[8], sum = { 0, 0, 0, 0 };
@@ -224,9 +229,11 @@ inline bool plan(int R, int nbc, SeaDev* d, size_t* lds_bytes)
         const int wgs = (int)((160 * 1024) / (bytes + 1024));           // allocation granularity slack
         const int waves = wgs * cand > 32 ? 32 : wgs * cand;
         const int per_row = (nbc + cand - 1) / cand;
-        // measured (NB sweep at 720x480): wave counts that spread evenly over the 4 SIMDs (8, 16) beat
-        // 15 by 13 % although 3 of 48 wave slots per block row idle -> small bonus for multiples of 4
-        const double score = waves * ((double)nbc / (per_row * cand)) + cand * 1e-3 + (cand % 4 == 0 ? 0.5 : 0.0);
+        // A workgroup's waves are dealt round robin to the CU's 4 SIMDs, so a wave count that is not a
+        // multiple of 4 leaves one SIMD with an extra wave for the whole search (measured: NB 16 vs 15
+        // +13 % at 720x480 sw 16; NB 8 vs 9 +17 % at 1080p sw 32) -> weigh by that imbalance.
+        const double simd_eff = (double)cand / (4 * ((cand + 3) / 4));
+        const double score = waves * ((double)nbc / (per_row * cand)) * simd_eff + cand * 1e-3;
         if (score > best_score) { best_score = score; nb = cand; }
     }
     if (const char* e = getenv("GME_SEA_NB")) nb = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));

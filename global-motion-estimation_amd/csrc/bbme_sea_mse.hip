@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     __syncthreads();
 
     // ---- A'
-    box_sums8<R>(d, win, s8);
+    box_sums8<R>(d, win, s8, (int)threadIdx.x);
     __syncthreads();
 
     // ---- B
@@ -269,6 +269,7 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const int nbr = job.H / 16, nbc = job.W / 16;
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
+    d.tile_ctr = nullptr;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;

@@ -42,8 +42,8 @@ extern "C" gme_ctx* gme_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->status, 256) != hipSuccess ||
-        hipMemsetAsync(ctx->status, 0, 256, ctx->stream) != hipSuccess ||
+        hipMalloc((void**)&ctx->status, 1024) != hipSuccess ||
+        hipMemsetAsync(ctx->status, 0, 1024, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         gme_set_error("gme_create: HIP initialisation failed on device %d: %s", device_id,
                       hipGetErrorString(hipGetLastError()));

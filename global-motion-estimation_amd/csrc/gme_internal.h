@@ -49,7 +49,8 @@ struct gme_ctx {
     // growable device scratch for the single-pair convenience calls
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    int* status = nullptr;        // device word set by kernels whose safety guards trip
+    int* status = nullptr;        // device word set by kernels whose safety guards trip; 1 KiB: words 64.. are the
+                                  // per-XCD tile counters of the persistent search kernels (16 words apart)
 };
 
 int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);

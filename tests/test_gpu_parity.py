@@ -343,6 +343,26 @@ def test_batched_exhaustive_is_pairwise(mods):
             assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + fd], 16, 16, 0, pn)), (fd, p)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_sea_schedules_agree(mods, monkeypatch, mode):
+    """k_exh_sea16 (one tile per workgroup, GME_SEA_PERSIST=0) and the persistent k_exh_sea16p with
+    the static (1) and the dynamic (2) tile schedule must all give the oracle's fields: ragged
+    block rows, pair counts that are not a multiple of the 8 XCDs, every window size class."""
+    native, bbme, _, _ = mods
+    monkeypatch.setenv("GME_SEA_PERSIST", mode)
+    ctx = native.default_context()
+    co = c_oracle()
+    for (n, h, w, sw, seed) in ((12, 96, 176, 16, 3), (4, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6)):
+        seq = native.Sequence(ctx, n, h, w)
+        seq.synth(seed, 0)
+        frames = [seq.read_frame(i) for i in range(n)]
+        seq.bbme(1, 16, sw, 0, 0)
+        mv = seq.read_mv()
+        for p in range(n - 1):
+            assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, 0, 0)), (mode, n, h, w, sw, p)
+        seq.close()
+
+
 def test_full_size_1080p(golden, mods):
     """BASELINE configs 4/5 sizes: exhaustive MSE sw=32 and the GME stages at 1920x1080."""
     native, bbme, motion, _ = mods

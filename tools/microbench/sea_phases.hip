@@ -31,7 +31,8 @@ int main(int argc, char** argv)
     uint8_t* dev; int32_t* mf; long long* stamps;
     CK(hipMalloc(&dev, host.size() + pitch)); CK(hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&mf, (size_t)pairs * 30 * 45 * 2 * 4));
-    gme_ctx ctx; CK(hipStreamCreate(&ctx.stream));
+    gme_ctx ctx; CK(hipStreamCreate(&ctx.stream)); CK(hipGetDeviceProperties(&ctx.prop, 0));
+    setenv("GME_SEA_PERSIST", "0", 1);                 // the stamps index by the plain kernel's 3-D grid
     BbmeJob job; job.prev = dev; job.cur = dev + stride; job.plane_stride = stride; job.pairs = pairs; job.H = H; job.W = W;
     job.pitch = pitch; job.bs = 16; job.sw = sw; job.procedure = 0; job.pnorm = 0; job.mf = mf; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
     // replicate launch_bbme_sea's setup, plus the stamp buffer
