@@ -183,7 +183,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             for (int i = 0; i < R; ++i) acc[i] = 0;
             if (active) {
                 const uint32_t* lrow = win + (prow2 * R + 4 * sub) * d.pitch_dw + w2 * 4 + q2 * R + k2;
-                const uint32_t* an = anchor + w2 * 64 + 16 * sub;
+                const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + 16 * sub;
     #pragma unroll
                 for (int t = 0; t < R + 3; ++t) {
                     uint64_t w[4];
@@ -193,9 +193,10 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
                     for (int i = 0; i < R; ++i) {
                         const int a = t - i;                   // anchor row 4*sub + a
                         if (a < 0 || a > 3) continue;
+                        const u32x4 ar = *(const u32x4*)(an + a * 4);
     #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], ar[j], acc[i]);
                     }
                 }
             }
@@ -262,7 +263,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
                 const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
                 const int prow2 = l2 >> 2, q2 = l2 & 3;
                 const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
-                const uint32_t* an = anchor + w2 * 64;
+                const uint32_t* an = anchor + w2 * ANCHOR_STRIDE;
                 uint64_t acc[R];
     #pragma unroll
                 for (int i = 0; i < R; ++i) acc[i] = 0;
@@ -275,9 +276,10 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
                     for (int i = 0; i < R; ++i) {
                         const int a = t - i;
                         if (a < 0 || a > 15) continue;
+                        const u32x4 ar = *(const u32x4*)(an + a * 4);
     #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], an[a * 4 + j], acc[i]);
+                            acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], ar[j], acc[i]);
                     }
                 }
                 const int c02 = (bcol0 + w2) * 16;
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     if (bcol0 + wave < d.nbc) {
         const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        lds[L.anchor + wave * 64 + lane] = mine;
+        lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
         anchor_quadrants(mine, &a01, &a23);
     }
     if (threadIdx.x == 0) lds[L.count] = 0;
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p(SeaDev d)
         const uint32_t mine = an_next;
         uint32_t a01 = 0, a23 = 0;
         if (bcol0_c + wave < d.nbc) {
-            lds[L.anchor + wave * 64 + lane] = mine;
+            lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
             anchor_quadrants(mine, &a01, &a23);
         }
         if (tid == 0) {

@@ -96,6 +96,11 @@ inline bool grid_for(const SeaDev& d, dim3* grid)
 
 // LDS carve-up shared by both kernels (dword offsets); `best` holds NB 64-bit slots so the MSE
 // kernel can keep 37-bit keys there (the MAE kernel uses the low dword of each).
+// Anchors sit 68 dwords apart, not 64: phase E lanes serving different blocks read the same anchor
+// element of "their" block at once, and a 64-dword stride would put all of those in one LDS bank.
+constexpr int ANCHOR_STRIDE = 68;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct Layout {
     int win, anchor, best, count, a2, s8, work, total;
 };
@@ -104,8 +109,8 @@ __host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int p
 {
     Layout l;
     l.win = 0;
-    l.anchor = win_rows * pitch_dw;
-    l.best = (l.anchor + nb * 64 + 1) & ~1;            // 8-byte aligned
+    l.anchor = (win_rows * pitch_dw + 3) & ~3;         // 16-byte aligned: anchor rows are read as b128
+    l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
     l.count = l.best + 2 * nb;
     l.a2 = l.count + 2;
     l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [16R+8][xq] u16x4

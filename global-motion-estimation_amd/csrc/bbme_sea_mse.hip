@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     if (wave_ok) {
         const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        anchor[wave * 64 + lane] = mine;
+        anchor[wave * ANCHOR_STRIDE + lane] = mine;
         anchor_quadrants(mine, &a01, &a23);
         mine2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
         const uint32_t a2 = wave_sum_u32(mine2);
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
             const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
             const int prow2 = l2 >> 2, q2 = l2 & 3;
             const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
-            const uint32_t* an = anchor + w2 * 64;
+            const uint32_t* an = anchor + w2 * ANCHOR_STRIDE;
             uint32_t acc[R][4];
 #pragma unroll
             for (int i = 0; i < R; ++i)
@@ -195,9 +195,10 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
                 for (int i = 0; i < R; ++i) {
                     const int a = t - i;
                     if (a < 0 || a > 15) continue;
+                    const u32x4 ar = *(const u32x4*)(an + a * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t av = an[a * 4 + j];
+                        const uint32_t av = ar[j];
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = __builtin_amdgcn_udot4(sh[j][e4], av, acc[i][e4], false);
                     }
