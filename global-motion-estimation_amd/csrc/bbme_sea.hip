@@ -356,96 +356,31 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     tile_phases<R, E4>(d, lds, L, pair, brow, bcol0, mine, a01, a23, (int)threadIdx.x);
 }
 
-// Persistent form: G workgroups (two per CU) walk the tiles of "their" XCD's pairs; the window and
-// anchor of the next tile are fetched into registers while the current one is searched, so the
-// HBM/L2 latency of phase A overlaps phases A' .. F instead of idling the workgroup's 16 waves.
+// What the shared persistent driver (bbme_sea_common.h: persistent_tiles) needs from this kernel.
+template <int R, bool E4>
+struct MaeTile {
+    struct Pre { uint32_t a01, a23; };
+    static __device__ __forceinline__ Pre prep(const SeaDev&, uint32_t* lds, const Layout& L, int wave, int lane, bool wave_ok, uint32_t mine)
+    {
+        Pre p = { 0, 0 };
+        if (wave_ok) {
+            lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
+            anchor_quadrants(mine, &p.a01, &p.a23);
+        }
+        return p;
+    }
+    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+                                                  uint32_t mine, const Pre& p, int tid)
+    {
+        tile_phases<R, E4>(d, lds, L, pair, brow, bcol0, mine, p.a01, p.a23, tid);
+    }
+};
+
 template <int R, int NV>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
-    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
-    const int xcd = blockIdx.x & 7, gx = gridDim.x >> 3;
-    const int npairs_x = (d.pairs - xcd + 7) >> 3;          // pairs with pair % 8 == xcd
-    const int ntiles = npairs_x * d.wg_per_pair;
-    int tile = blockIdx.x >> 3;
-    if (tile >= ntiles) return;
-
-    // Everything derived from the thread index is recomputed per tile from an opaque copy (the empty
-    // asm): hoisted out of the tile loop those values cost more registers than the 64 that eight
-    // waves per SIMD allow, and a spill reload (vmcnt) would wait for the prefetch it sits behind.
-    uint32_t wv[NV], an_next = 0;
-    int pair = 0, brow = 0, bcol0 = 0;
-    auto fetch = [&](int t) {
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const int row0 = div_small(tid, d.magic_pitch), dw = tid - row0 * d.pitch_dw;
-        const int lp = (int)(((unsigned long long)(unsigned)t * d.magic_wpp) >> 40);
-        const int wg = t - lp * d.wg_per_pair;
-        brow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
-        bcol0 = (wg - brow * d.wg_per_row) * d.nb;
-        pair = lp * 8 + xcd;
-        const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-        const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = brow * 16 - d.sw + row0;
-        const bool colok = row0 < d.rstep && gx0 >= 0 && gx0 < d.pitch;
-        const uint8_t* src = cur + (long long)gy0 * d.pitch + gx0;
-        const long long sstep = (long long)d.rstep * d.pitch;
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int gy = gy0 + u * d.rstep;
-            wv[u] = 0;
-            if (colok && row0 + u * d.rstep < d.win_rows && gy >= 0 && gy < d.H) wv[u] = *(const uint32_t*)(src + u * sstep);
-        }
-        an_next = 0;
-        if (bcol0 + wave < d.nbc) {
-            const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
-            an_next = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        }
-    };
-    fetch(tile);
-    // Dynamic schedule (d.tile_ctr): after its first tile a workgroup draws tile numbers gx + n from its
-    // XCD's counter.  Thread 0 asks one tile ahead, so the atomic's round trip is waited for together
-    // with the prefetched window (same vmcnt), never on its own.
-    uint32_t* ctr = d.tile_ctr ? d.tile_ctr + 16 * xcd : nullptr;
-    uint32_t drawn = 0;
-    if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);   // not atomicAdd: LLVM would aggregate it over the wave and wait for the result at once
-    for (;;) {
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        // registers -> LDS
-        {
-            const int row0 = div_small(tid, d.magic_pitch);
-            if (row0 < d.rstep) {
-                uint32_t* dst = lds + L.win + tid;
-                const int dstep = d.rstep * d.pitch_dw;
-#pragma unroll
-                for (int u = 0; u < NV; ++u)
-                    if (row0 + u * d.rstep < d.win_rows) dst[u * dstep] = wv[u];
-            }
-        }
-        const int pair_c = pair, brow_c = brow, bcol0_c = bcol0;
-        const uint32_t mine = an_next;
-        uint32_t a01 = 0, a23 = 0;
-        if (bcol0_c + wave < d.nbc) {
-            lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
-            anchor_quadrants(mine, &a01, &a23);
-        }
-        if (tid == 0) {
-            lds[L.count] = 0;
-            if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
-        }
-        __syncthreads();
-        tile = ctr ? (int)lds[L.count + 1] : tile + gx;
-        const bool more = tile < ntiles;                   // workgroup-uniform
-        if (more) {
-            fetch(tile);
-            if (ctr && tid == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);   // not atomicAdd: LLVM would aggregate it over the wave and wait for the result at once
-        }
-        tile_phases<R, false>(d, lds, L, pair_c, brow_c, bcol0_c, mine, a01, a23, tid);
-        if (!more) break;
-        __syncthreads();                                   // everyone is done with this tile's LDS
-    }
+    persistent_tiles<NV, MaeTile<R, (R >= 4)>>(d, lds, make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq));
 }
 
 }  // namespace
@@ -484,23 +419,12 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.magic_wpp = div_magic40(d.wg_per_pair);
     d.magic_wpr = div_magic40(d.wg_per_row);
     const dim3 block(64 * d.nb);
-    const long long tiles_x = (((long long)job.pairs + 7) / 8) * d.wg_per_pair;      // per XCD
-    const int nv = (d.win_rows + d.rstep - 1) / d.rstep;
-    // Persistent form by default when every resident workgroup gets several tiles; GME_SEA_PERSIST = 0
-    // forces the one-tile-per-workgroup kernel, 1 / 2 force the persistent one (static / dynamic schedule).
-    const char* pmode = getenv("GME_SEA_PERSIST");
-    const int pm = pmode ? atoi(pmode) : -1;
-    int per_cu = (int)((160 * 1024) / (lds + 1024));           // resident workgroups per CU: LDS, 32 wave slots
-    if (per_cu * d.nb > 32) per_cu = 32 / d.nb;
-    if (per_cu < 1) per_cu = 1;
-    long long g = (long long)per_cu * ctx->prop.multiProcessorCount / 8;            // per XCD
-    const bool can_persist = tiles_x < (1ll << 21) && d.wg_per_pair < (1 << 18) && nv <= 16 && g >= 1;
-    const bool persist = can_persist && (pm > 0 || (pm < 0 && tiles_x >= 4 * g));
-    if (persist) {
-        if (g > tiles_x) g = tiles_x;
-        const dim3 grid((unsigned)(8 * g));
+    const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
+    const int nv = pp.nv;
+    if (pp.use) {
+        const dim3 grid((unsigned)(8 * pp.g));
         d.tile_ctr = nullptr;
-        if (pm != 1) {
+        if (pp.dynamic) {
             d.tile_ctr = (uint32_t*)ctx->status + 64;
             GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
@@ -519,7 +443,9 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     } else {
     dim3 grid;
     GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
-    const bool e4 = getenv("GME_SEA_E4") != nullptr;           // A/B switch for phase E (4 lanes per patch)
+    // phase E with four lanes per patch pays for the large windows (measured: +11 % at sw 32, even at
+    // sw 16); GME_SEA_E4 = 0 / 1 overrides it for this one-tile kernel
+    const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : R >= 4;
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
     switch (R) {

@@ -254,4 +254,118 @@ inline bool plan(int R, int nbc, SeaDev* d, size_t* lds_bytes)
     return *lds_bytes <= 160 * 1024 && d->pitch_dw < 256 && d->xq < 256;
 }
 
+
+// Persistent form of a search kernel: G workgroups (as many as fit on the chip at once) walk the
+// tiles of "their" XCD's pairs.  The window and anchor of the next tile are fetched into registers
+// while the current one is searched, so the HBM/L2 latency of phase A overlaps phases A' .. F
+// instead of idling the workgroup's waves.  Kern supplies prep() (anchor -> LDS, per-wave anchor
+// statistics) and phases() (A' .. F).
+//
+// Schedule: static (tile += G/8) or, with d.tile_ctr, dynamic: after its first tile a workgroup
+// draws tile numbers G/8 + n from its XCD's counter.  Thread 0 asks one tile ahead, so the
+// atomic's round trip is waited for together with the prefetched window (same vmcnt).  It is an
+// atomicInc, not atomicAdd: LLVM would aggregate an add over the wave and wait for its result at once.
+//
+// Everything derived from the thread index is recomputed per tile from an opaque copy (the empty
+// asm): hoisted out of the tile loop those values cost more registers than the 64 that eight
+// waves per SIMD allow, and a spill reload (vmcnt) would wait for the prefetch it sits behind.
+template <int NV, class Kern>
+__device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds, const Layout L)
+{
+    const int xcd = blockIdx.x & 7, gx = gridDim.x >> 3;
+    const int npairs_x = (d.pairs - xcd + 7) >> 3;          // pairs with pair % 8 == xcd
+    const int ntiles = npairs_x * d.wg_per_pair;
+    int tile = blockIdx.x >> 3;
+    if (tile >= ntiles) return;
+
+    uint32_t wv[NV], an_next = 0;
+    int pair = 0, brow = 0, bcol0 = 0;
+    auto fetch = [&](int t) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int row0 = div_small(tid, d.magic_pitch), dw = tid - row0 * d.pitch_dw;
+        const int lp = (int)(((unsigned long long)(unsigned)t * d.magic_wpp) >> 40);
+        const int wg = t - lp * d.wg_per_pair;
+        brow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
+        bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+        pair = lp * 8 + xcd;
+        const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+        const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = brow * 16 - d.sw + row0;
+        const bool colok = row0 < d.rstep && gx0 >= 0 && gx0 < d.pitch;
+        const uint8_t* src = cur + (long long)gy0 * d.pitch + gx0;
+        const long long sstep = (long long)d.rstep * d.pitch;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int gy = gy0 + u * d.rstep;
+            wv[u] = 0;
+            if (colok && row0 + u * d.rstep < d.win_rows && gy >= 0 && gy < d.H) wv[u] = *(const uint32_t*)(src + u * sstep);
+        }
+        an_next = 0;
+        if (bcol0 + wave < d.nbc) {
+            const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+            an_next = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        }
+    };
+    fetch(tile);
+    uint32_t* ctr = d.tile_ctr ? d.tile_ctr + 16 * xcd : nullptr;
+    uint32_t drawn = 0;
+    if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
+    for (;;) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        {   // registers -> LDS
+            const int row0 = div_small(tid, d.magic_pitch);
+            if (row0 < d.rstep) {
+                uint32_t* dst = lds + L.win + tid;
+                const int dstep = d.rstep * d.pitch_dw;
+#pragma unroll
+                for (int u = 0; u < NV; ++u)
+                    if (row0 + u * d.rstep < d.win_rows) dst[u * dstep] = wv[u];
+            }
+        }
+        const int pair_c = pair, brow_c = brow, bcol0_c = bcol0;
+        const uint32_t mine = an_next;
+        const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, bcol0_c + wave < d.nbc, mine);
+        if (tid == 0) {
+            lds[L.count] = 0;
+            if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
+        }
+        __syncthreads();
+        tile = ctr ? (int)lds[L.count + 1] : tile + gx;
+        const bool more = tile < ntiles;                   // workgroup-uniform
+        if (more) {
+            fetch(tile);
+            if (ctr && tid == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
+        }
+        Kern::phases(d, lds, L, pair_c, brow_c, bcol0_c, mine, pre, tid);
+        if (!more) break;
+        __syncthreads();                                   // everyone is done with this tile's LDS
+    }
+}
+
+// Host side of the persistent form: resident workgroups per XCD (what LDS and the 32 wave slots of
+// a CU allow, on every CU) and whether the launch qualifies.  GME_SEA_PERSIST = 0 forces the
+// one-tile-per-workgroup kernel, 1 / 2 force the persistent one (static / dynamic schedule);
+// unset: persistent with the dynamic schedule once every resident workgroup gets several tiles.
+struct PersistPlan { bool use; bool dynamic; long long g; int nv; };
+inline PersistPlan plan_persistent(const SeaDev& d, size_t lds_bytes, int pairs, int cu_count)
+{
+    PersistPlan p;
+    const long long tiles_x = (((long long)pairs + 7) / 8) * d.wg_per_pair;          // per XCD
+    p.nv = (d.win_rows + d.rstep - 1) / d.rstep;
+    const char* pmode = getenv("GME_SEA_PERSIST");
+    const int pm = pmode ? atoi(pmode) : -1;
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
+    if (per_cu * d.nb > 32) per_cu = 32 / d.nb;
+    if (per_cu < 1) per_cu = 1;
+    p.g = (long long)per_cu * cu_count / 8;
+    const bool can = tiles_x < (1ll << 21) && d.wg_per_pair < (1 << 18) && p.nv <= 16 && p.g >= 1;
+    p.use = can && (pm > 0 || (pm < 0 && tiles_x >= 4 * p.g));
+    p.dynamic = pm != 1;
+    if (p.g > tiles_x) p.g = tiles_x;
+    return p;
+}
+
 }  // namespace sea

@@ -62,13 +62,13 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
     }
 }
 
-template <int R>
-__global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
+// Phases A' .. F of one tile (entry conditions as tile_phases() of bbme_sea.hip, plus a2s[] filled).
+template <int R, bool E4>
+__device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+                                                uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid)
 {
-    extern __shared__ uint32_t lds[];
-    const int NB = d.nb, T = blockDim.x;
+    const int T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
-    const Layout L = make_layout(R, NB, d.win_rows, d.pitch_dw, XQ);
     uint32_t* win = lds + L.win;
     uint32_t* anchor = lds + L.anchor;
     unsigned long long* best = (unsigned long long*)(lds + L.best);     // [NB] ssd << 13 | scan index
@@ -76,35 +76,16 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     uint32_t* a2s = lds + L.a2;                                         // [NB] sum of squares of each anchor
     uint64_t* s8 = (uint64_t*)(lds + L.s8);
     uint32_t* work = lds + L.work;
-
-    int pair, brow, bcol0;
-    if (!locate(d, &pair, &brow, &bcol0)) return;
     const int r0 = brow * 16;
-    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int bcol = bcol0 + wave;
     const bool wave_ok = bcol < d.nbc;
     const int c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
 
-    // ---- A
-    stage_window(d, win, cur, bcol0, r0);
-    uint32_t mine = 0, a01 = 0, a23 = 0, mine2 = 0;
-    if (wave_ok) {
-        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
-        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        anchor[wave * ANCHOR_STRIDE + lane] = mine;
-        anchor_quadrants(mine, &a01, &a23);
-        mine2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
-        const uint32_t a2 = wave_sum_u32(mine2);
-        if (lane == 0) a2s[wave] = a2;
-    }
-    if (threadIdx.x == 0) *count = 0;
-    __syncthreads();
-
     // ---- A'
-    box_sums8<R>(d, win, s8, (int)threadIdx.x);
+    box_sums8<R>(d, win, s8, tid);
     __syncthreads();
 
     // ---- B
@@ -158,29 +139,33 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     }
     __syncthreads();
 
-    // ---- E
+    // ---- E: LPP lanes per listed patch; lane `sub` takes anchor rows AR*sub .. AR*sub+AR-1 (R+AR-1 window
+    // rows), the partial dot products are added inside the quad with DPP moves.  Four lanes per patch
+    // repeat some v_alignbyte work but put four times as many waves on the (long) evaluation.
+    constexpr int LPP = E4 ? 4 : 1, AR = 16 / LPP;
     const int n = (int)*count;
     const uint32_t* tab = d.sqbox + (long long)pair * d.sqbox_stride;
-    for (int base = 0; base < n; base += T) {
-        const int e = base + threadIdx.x;
+    for (int base = 0; base < n; base += T / LPP) {
+        const int e = base + tid / LPP;
+        const int sub = E4 ? (lane & 3) : 0;
         bool active = e < n;
         uint32_t ent = 0;
         if (active) {
             ent = work[e];
             active = (ent & 0xFFFFu) <= (uint32_t)(best[ent >> 25] >> 21);
         }
+        const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+        const int prow2 = l2 >> 2, q2 = l2 & 3;
+        uint32_t acc[R][4];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = 0;
         if (active) {
-            const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
-            const int prow2 = l2 >> 2, q2 = l2 & 3;
-            const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
-            const uint32_t* an = anchor + w2 * ANCHOR_STRIDE;
-            uint32_t acc[R][4];
+            const uint32_t* lrow = win + (prow2 * R + AR * sub) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+            const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + AR * 4 * sub;
 #pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = 0;
-#pragma unroll
-            for (int t = 0; t < R + 15; ++t) {
+            for (int t = 0; t < R + AR - 1; ++t) {
                 uint32_t w[5];
 #pragma unroll
                 for (int s = 0; s < 5; ++s) w[s] = lrow[t * d.pitch_dw + s];
@@ -194,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int a = t - i;
-                    if (a < 0 || a > 15) continue;
+                    if (a < 0 || a > AR - 1) continue;
                     const u32x4 ar = *(const u32x4*)(an + a * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -209,6 +194,17 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) asm volatile("" : "+v"(acc[i][e4]));
             }
+        }
+        if (E4) {                                          // quads are uniform in `active` (one entry per quad)
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    acc[i][e4] += SEA_DPP(acc[i][e4], 0xB1);                     // quad_perm [1,0,3,2]
+                    acc[i][e4] += SEA_DPP(acc[i][e4], 0x4E);                     // quad_perm [2,3,0,1]
+                }
+        }
+        if (active && sub == 0) {
             const int c02 = (bcol0 + w2) * 16;
             const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
             const uint32_t a2 = a2s[w2];
@@ -257,6 +253,58 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     }
 }
 
+template <int R, bool E4>
+struct MseTile {
+    struct Pre { uint32_t a01, a23, mine2; };
+    static __device__ __forceinline__ Pre prep(const SeaDev&, uint32_t* lds, const Layout& L, int wave, int lane, bool wave_ok, uint32_t mine)
+    {
+        Pre p = { 0, 0, 0 };
+        if (wave_ok) {
+            lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
+            anchor_quadrants(mine, &p.a01, &p.a23);
+            p.mine2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
+            const uint32_t a2 = wave_sum_u32(p.mine2);
+            if (lane == 0) lds[L.a2 + wave] = a2;
+        }
+        return p;
+    }
+    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+                                                  uint32_t mine, const Pre& p, int tid)
+    {
+        tile_phases_mse<R, E4>(d, lds, L, pair, brow, bcol0, mine, p.a01, p.a23, p.mine2, tid);
+    }
+};
+
+template <int R, bool E4>
+__global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
+    int pair, brow, bcol0;
+    if (!locate(d, &pair, &brow, &bcol0)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // ---- A
+    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    uint32_t mine = 0;
+    const bool wave_ok = bcol0 + wave < d.nbc;
+    if (wave_ok) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+    }
+    const typename MseTile<R, E4>::Pre pre = MseTile<R, E4>::prep(d, lds, L, wave, lane, wave_ok, mine);
+    if (threadIdx.x == 0) lds[L.count] = 0;
+    __syncthreads();
+    MseTile<R, E4>::phases(d, lds, L, pair, brow, bcol0, mine, pre, (int)threadIdx.x);
+}
+
+template <int R, int NV>
+__global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p_mse(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    persistent_tiles<NV, MseTile<R, false>>(d, lds, make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq));
+}
+
 }  // namespace
 
 int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
@@ -281,15 +329,47 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     size_t lds = 0;
     if (!plan(R, nbc, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
     d.wg_per_pair = d.wg_per_row * nbr;
-    dim3 grid;
-    GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+    d.magic_wpp = div_magic40(d.wg_per_pair);
+    d.magic_wpr = div_magic40(d.wg_per_row);
     const dim3 block(64 * d.nb);
-    switch (R) {
-    case 1: hipLaunchKernelGGL(k_exh_sea16_mse<1>, grid, block, lds, ctx->stream, d); break;
-    case 2: hipLaunchKernelGGL(k_exh_sea16_mse<2>, grid, block, lds, ctx->stream, d); break;
-    case 3: hipLaunchKernelGGL(k_exh_sea16_mse<3>, grid, block, lds, ctx->stream, d); break;
-    case 4: hipLaunchKernelGGL(k_exh_sea16_mse<4>, grid, block, lds, ctx->stream, d); break;
-    default: hipLaunchKernelGGL(k_exh_sea16_mse<5>, grid, block, lds, ctx->stream, d); break;
+    const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
+    const int nv = pp.nv;
+    // The persistent form must hold the prefetched tile in registers next to phase E's 4R accumulators;
+    // at R = 3 (and R = 2 with many staging rows) that exceeds the 64 VGPRs of 8 waves/SIMD and the
+    // compiler would spill the prefetch itself -> those sizes keep the one-tile kernel.
+    const bool fits = R <= 1 || (R == 2 && nv <= 8) || R >= 4;
+    if (pp.use && fits) {
+        const dim3 grid((unsigned)(8 * pp.g));
+        if (pp.dynamic) {
+            d.tile_ctr = (uint32_t*)ctx->status + 64;
+            GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+        }
+#define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p_mse<RR, NVV>), grid, block, lds, ctx->stream, d)
+#define SEA_LAUNCH_PN(RR) do { if (nv <= 6) SEA_LAUNCH_P(RR, 6); else if (nv <= 8) SEA_LAUNCH_P(RR, 8); \
+                               else if (nv <= 12) SEA_LAUNCH_P(RR, 12); else SEA_LAUNCH_P(RR, 16); } while (0)
+        switch (R) {
+        case 1: SEA_LAUNCH_PN(1); break;
+        case 2: SEA_LAUNCH_PN(2); break;
+        case 3: SEA_LAUNCH_PN(3); break;
+        case 4: SEA_LAUNCH_PN(4); break;
+        default: SEA_LAUNCH_PN(5); break;
+        }
+#undef SEA_LAUNCH_PN
+#undef SEA_LAUNCH_P
+    } else {
+        dim3 grid;
+        GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+        const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : false;   // measured: four lanes per patch lose 9 % here (repeated v_alignbyte work)
+#define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16_mse<RR, true>), grid, block, lds, ctx->stream, d); \
+                            else hipLaunchKernelGGL((k_exh_sea16_mse<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
+        switch (R) {
+        case 1: SEA_LAUNCH(1); break;
+        case 2: SEA_LAUNCH(2); break;
+        case 3: SEA_LAUNCH(3); break;
+        case 4: SEA_LAUNCH(4); break;
+        default: SEA_LAUNCH(5); break;
+        }
+#undef SEA_LAUNCH
     }
     GME_HIP_TRY(hipGetLastError());
     *handled = true;

@@ -345,9 +345,9 @@ def test_batched_exhaustive_is_pairwise(mods):
 
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_sea_schedules_agree(mods, monkeypatch, mode):
-    """k_exh_sea16 (one tile per workgroup, GME_SEA_PERSIST=0) and the persistent k_exh_sea16p with
-    the static (1) and the dynamic (2) tile schedule must all give the oracle's fields: ragged
-    block rows, pair counts that are not a multiple of the 8 XCDs, every window size class."""
+    """k_exh_sea16[_mse] (one tile per workgroup, GME_SEA_PERSIST=0) and the persistent k_exh_sea16p[_mse]
+    with the static (1) and the dynamic (2) tile schedule must all give the oracle's fields: ragged
+    block rows, pair counts that are not a multiple of the 8 XCDs, every window size class, both norms."""
     native, bbme, _, _ = mods
     monkeypatch.setenv("GME_SEA_PERSIST", mode)
     ctx = native.default_context()
@@ -356,10 +356,11 @@ def test_sea_schedules_agree(mods, monkeypatch, mode):
         seq = native.Sequence(ctx, n, h, w)
         seq.synth(seed, 0)
         frames = [seq.read_frame(i) for i in range(n)]
-        seq.bbme(1, 16, sw, 0, 0)
-        mv = seq.read_mv()
-        for p in range(n - 1):
-            assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, 0, 0)), (mode, n, h, w, sw, p)
+        for pn in (0, 1):
+            seq.bbme(1, 16, sw, 0, pn)
+            mv = seq.read_mv()
+            for p in range(n - 1):
+                assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, 0, pn)), (mode, n, h, w, sw, pn, p)
         seq.close()
 
 
