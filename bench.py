@@ -251,7 +251,7 @@ def main():
                        "sharding": "frame pairs across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_exh_sea16<3>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
+                         "kernel": "k_exh_sea16p<3, 6>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
                                    ("whole step (all kernels + host solves)" if gme else "see DESIGN.md"),
                          "kernel_ms_per_launch": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes},
@@ -265,8 +265,9 @@ def main():
             vals = {}
             for line in open(prof):
                 f = line.split()
-                if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    vals[f[1]] = float(f[-1].split("=")[1])
+                for name in ("FETCH_SIZE", "WRITE_SIZE"):
+                    if name in f and not line.startswith("#"):
+                        vals[name] = float(f[-1].split("=")[1])
             if len(vals) == 2:
                 out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
                 out["roofline"]["traffic_unit"] = "bytes per launch, from profiles/r01_final_exh720_pmc_summary.txt"
