@@ -253,38 +253,63 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         for (int k = 0; k < 8; ++k) if (grp == k) { my_dr = ldr[k]; my_dc = ldc[k]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (grp == k) { my_sr = sdr[k]; my_sc = sdc[k]; }
+        // Winner of a pattern without leaving the vector unit: every lane of group k holds candidate k's
+        // cost, key = cost << 3 | k (cost < 2^24), minimum over the 8 groups by one DPP rotate inside
+        // each 16-lane row plus four v_readlane.  Only a key whose cost is strictly below the centre's
+        // moves the centre (bbme.py:507-510: first strict minimum, the centre is candidate 0); the
+        // winner's offset comes out of nibble tables, so no per-candidate scalar position is needed.
+#define PATTERN_MIN(n, RRV, CCV, RMIN, RMAX, CMIN, CMAX, KMIN)                                        \
+    do {                                                                                             \
+        if (!(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 &&         \
+              (CMAX) <= wc0 + WIN_SPAN)) {                                                           \
+            wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                                  \
+            wc0 = ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3;                            \
+            stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
+            have_win = true;                                                                         \
+        }                                                                                            \
+        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, wr0, wc0, RRV, CCV, grp < (n), lrow);  \
+        unsigned key_ = grp < (n) ? (c_ << 3) | (unsigned)grp : INF32;                               \
+        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x128, 0xF, 0xF, false)); /* row_ror 8 */ \
+        const unsigned k0_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 0), k1_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 16); \
+        const unsigned k2_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 32), k3_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 48); \
+        KMIN = min(min(k0_, k1_), min(k2_, k3_));                                                    \
+    } while (0)
         int it = 0;
         for (;;) {
-            // candidate 0 of the pattern is the clamped centre itself
-            unsigned best = centre_cost;
-            int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
-            int cr[8], cc[8]; unsigned cost[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { cr[k] = clamp_ref(pr + ldr[k], maxr); cc[k] = clamp_ref(pc + ldc[k], maxc); }
             const int rrv = clamp_ref(pr + my_dr, maxr), ccv = clamp_ref(pc + my_dc, maxc);
-            EVALP(8, rrv, ccv, clamp_ref(pr - 2, maxr), clamp_ref(pr + 2, maxr), clamp_ref(pc - 2, maxc),
-                  clamp_ref(pc + 2, maxc), cost);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            unsigned kmin;
+            PATTERN_MIN(8, rrv, ccv, clamp_ref(pr - 2, maxr), clamp_ref(pr + 2, maxr), clamp_ref(pc - 2, maxc),
+                        clamp_ref(pc + 2, maxc), kmin);
+            // candidate 0 of the pattern is the clamped centre itself
+            int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
+            if ((kmin >> 3) < centre_cost) {
+                const unsigned k = kmin & 7u;
+                // ldr + 2 = 4,3,2,1,0,1,2,3 and ldc + 2 = 2,3,4,3,2,1,0,1 as nibbles, k = 0 lowest
+                br = clamp_ref(pr + (int)((0x32101234u >> (4 * k)) & 15u) - 2, maxr);
+                bc = clamp_ref(pc + (int)((0x10123432u >> (4 * k)) & 15u) - 2, maxc);
+                centre_cost = kmin >> 3;
+            }
             const bool done = (br == pr && bc == pc);
-            pr = br; pc = bc; centre_cost = best;              // next centre is already clamped
+            pr = br; pc = bc;                                  // next centre is already clamped
             if (done) break;
             if (++it > cap) { overrun = true; break; }
         }
         // small pattern, offsets applied swapped (bbme.py:518-521): (0,0),(1,0),(0,1),(-1,0),(0,-1) -> row += o[1], col += o[0]
         {
-            unsigned best = centre_cost;
             int br = pr, bc = pc;
-            int cr[4], cc[4]; unsigned cost[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { cr[k] = clamp_ref(pr + sdr[k], maxr); cc[k] = clamp_ref(pc + sdc[k], maxc); }
             const int rrv = clamp_ref(pr + my_sr, maxr), ccv = clamp_ref(pc + my_sc, maxc);
-            EVALP(4, rrv, ccv, clamp_ref(pr - 1, maxr), clamp_ref(pr + 1, maxr), clamp_ref(pc - 1, maxc),
-                  clamp_ref(pc + 1, maxc), cost);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            unsigned kmin;
+            PATTERN_MIN(4, rrv, ccv, clamp_ref(pr - 1, maxr), clamp_ref(pr + 1, maxr), clamp_ref(pc - 1, maxc),
+                        clamp_ref(pc + 1, maxc), kmin);
+            if ((kmin >> 3) < centre_cost) {
+                const unsigned k = kmin & 3u;
+                // sdr + 1 = 1,2,1,0 and sdc + 1 = 2,1,0,1 as nibbles
+                br = clamp_ref(pr + (int)((0x0121u >> (4 * k)) & 15u) - 1, maxr);
+                bc = clamp_ref(pc + (int)((0x1012u >> (4 * k)) & 15u) - 1, maxc);
+            }
             out1 = br - r0; out0 = bc - c0;
         }
+#undef PATTERN_MIN
     } else if (d.procedure == GME_SEARCH_THREESTEP) {
         const int n = 2 * d.sw + 16;
         const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };

@@ -365,6 +365,14 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     delete s;
 }
 
+// new frame data ends a staged GME run: searches gme_seq_gme_begin deferred must not see other frames
+// than the stages already done, so the run is dropped (gme_seq_gme_fit then asks for a new begin)
+static void gme_drop_run(gme_seq* s)
+{
+    s->bbme_pending[0] = s->bbme_pending[1] = s->bbme_pending[2] = false;
+    s->gme_pairs = 0;
+}
+
 extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* frames, int row_stride,
                               int64_t frame_stride)
 {
@@ -385,6 +393,7 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
     }
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
+    gme_drop_run(s);
     GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // the host buffer may be reused on return
     return GME_OK;
 }
@@ -408,6 +417,7 @@ extern "C" int gme_seq_synth(gme_seq* s, uint64_t seed, int t0)
     }
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
+    gme_drop_run(s);
     return launch_synth_frames(s->ctx, seed, t0, s->synth_canvas, s->level[2]);
 }
 
@@ -416,6 +426,7 @@ extern "C" int gme_seq_invalidate(gme_seq* s)
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
+    gme_drop_run(s);
     return GME_OK;
 }
 
@@ -525,6 +536,43 @@ static int alloc_fit(FitLevelBuf& f, int pairs, int h, int w, bool full)
     return GME_OK;
 }
 
+
+// BBME of one pyramid level for the pairs of the current GME run (gme_seq_gme_begin's arguments):
+// level 0 = dense field (bs 2, diamond, MSE: motion.py:27-29; bbme.py:18 default norm).
+static int gme_level_bbme(gme_seq* s, int l)
+{
+    if (!s->bbme_pending[l]) return GME_OK;
+    s->bbme_pending[l] = false;
+    const Plane& p = s->level[l];
+    const int fd = s->gme_fd;
+    BbmeJob job;
+    job.prev = p.at(0); job.cur = p.at(fd); job.plane_stride = p.stride; job.pairs = s->gme_pairs;
+    job.H = p.H; job.W = p.W; job.pitch = p.pitch;
+    job.bs = l == 0 ? 2 : s->gme_bs;
+    job.sw = l == 0 ? 2 : s->gme_sw;
+    job.procedure = l == 0 ? GME_SEARCH_DIAMOND : s->gme_procedure;
+    job.pnorm = GME_NORM_MSE;
+    job.mf = s->fit[l].gt; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+    if (s->fit[l].h == 0 || s->fit[l].w == 0) return GME_OK;
+    if (const int aux = bbme_aux_kind(job.bs, job.sw, job.procedure, job.pnorm)) {      // BASELINE config 4
+        const int rc = seq_sqbox(s, l, aux);
+        if (rc) return rc;
+        job.sqbox_cur = s->sqbox[l] + (size_t)fd * p.stride;
+        job.sqbox_stride = p.stride;
+    }
+    return launch_bbme(s->ctx, job);
+}
+
+// launch whatever gme_seq_gme_begin deferred, up to and including `level`
+static int gme_flush_bbme(gme_seq* s, int level)
+{
+    for (int l = 0; l <= level && l <= 2; ++l) {
+        const int rc = gme_level_bbme(s, l);
+        if (rc) return rc;
+    }
+    return GME_OK;
+}
+
 extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, float* params0_out)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
@@ -575,36 +623,26 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
         s->gme_alloc_pairs = pairs;
     }
     s->gme_fd = fd; s->gme_bs = bbme_bs; s->gme_pairs = pairs;
-    // dense field on the coarsest level: bs 2, diamond, MSE (motion.py:27-29; bbme.py:18 default norm)
-    for (int l = 0; l <= 2; ++l) {
-        const Plane& p = s->level[l];
-        BbmeJob job;
-        job.prev = p.at(0); job.cur = p.at(fd); job.plane_stride = p.stride; job.pairs = pairs;
-        job.H = p.H; job.W = p.W; job.pitch = p.pitch;
-        job.bs = l == 0 ? 2 : bbme_bs;
-        job.sw = l == 0 ? 2 : sw;
-        job.procedure = l == 0 ? GME_SEARCH_DIAMOND : procedure;
-        job.pnorm = GME_NORM_MSE;
-        job.mf = s->fit[l].gt; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
-        if (s->fit[l].h == 0 || s->fit[l].w == 0) continue;
-        if (const int aux = bbme_aux_kind(job.bs, job.sw, job.procedure, job.pnorm)) {      // BASELINE config 4
-            rc = seq_sqbox(s, l, aux);
-            if (rc) return rc;
-            job.sqbox_cur = s->sqbox[l] + (size_t)fd * p.stride;
-            job.sqbox_stride = p.stride;
-        }
-        rc = launch_bbme(ctx, job);
-        if (rc) return rc;
-    }
+    s->gme_procedure = procedure; s->gme_sw = sw;
+    s->bbme_pending[0] = s->bbme_pending[1] = s->bbme_pending[2] = true;
+    // Launch order: dense field + first parameters, hand those to the host, and only then the level-1
+    // search; the level-2 search (the longest kernel) is launched by gme_seq_gme_fit(level 1) after
+    // it has the level-1 sums.  The host's projection / 3x3 solves between the stages then run
+    // while the GPU searches the next level instead of leaving it idle (motion.py:123-136 is a
+    // strict chain only through the small fits, not through the searches).
+    rc = gme_level_bbme(s, 0);
+    if (rc) return rc;
     GME_REQUIRE(s->fit[0].h > 0 && s->fit[0].w > 0, GME_ERR_GEOMETRY, "frames too small for a dense field");
     rc = launch_first_params(ctx, s->fit[0].gt, pairs, s->fit[0].h * s->fit[0].w, s->params0);
     if (rc) return rc;
     if (params0_out) {
         GME_HIP_TRY(hipMemcpyAsync(params0_out, s->params0, (size_t)pairs * 6 * sizeof(float), hipMemcpyDeviceToHost,
                                    ctx->stream));
-        return ctx_finish(ctx);
+        rc = ctx_finish(ctx);
+        if (rc) return rc;
+        return gme_level_bbme(s, 1);                       // runs while the caller projects the parameters
     }
-    return GME_OK;
+    return gme_flush_bbme(s, 2);
 }
 
 static int ensure_fit_mv(gme_seq* s)
@@ -657,6 +695,8 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
         dparams = s->mv_params;
     } else {
         GME_REQUIRE(s->gme_pairs > 0 && s->params_in, GME_ERR_STATE, "gme_seq_gme_fit before gme_seq_gme_begin");
+        rc = gme_flush_bbme(s, level);
+        if (rc) return rc;
         f = &s->fit[level]; pairs = s->gme_pairs; level_H = s->level[level].H; level_W = s->level[level].W;
         dparams = s->params_in;
     }
@@ -670,7 +710,10 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
                           f->thr, f->sums, f->list);
     if (rc) return rc;
     GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    return ctx_finish(ctx);
+    rc = ctx_finish(ctx);
+    if (rc) return rc;
+    if (level == 1) return gme_level_bbme(s, 2);           // searched while the caller solves level 1
+    return GME_OK;
 }
 
 extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* gt, int16_t* model, uint8_t* mask,
@@ -682,6 +725,10 @@ extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* 
     if (rc) return rc;
     GME_REQUIRE(level >= -1 && level <= 2 && pair >= 0 && pair < (level < 0 ? s->fit_mv_pairs : s->gme_pairs), GME_ERR_ARG,
                 "gme_seq_gme_read_stage: bad index");
+    if (level >= 0) {
+        rc = gme_flush_bbme(s, level);
+        if (rc) return rc;
+    }
     const FitLevelBuf& f = level < 0 ? s->fit_mv : s->fit[level];
     const size_t n = (size_t)f.h * f.w;
     int32_t thr = 0;

@@ -85,6 +85,8 @@ struct gme_seq {
     size_t sqtmp_bytes = 0;
     // GME state
     int gme_fd = 0, gme_bs = 0, gme_pairs = 0;
+    int gme_procedure = 0, gme_sw = 0;
+    bool bbme_pending[3] = { false, false, false };   // level searches gme_seq_gme_begin deferred (see there)
     FitLevelBuf fit[3];           // fit[0].gt = dense field
     FitLevelBuf fit_mv;           // stage buffers for fitting `mv` directly (gt not owned)
     int fit_mv_pairs = 0;

@@ -121,7 +121,11 @@ GME_API int gme_seq_read_mv(gme_seq *seq, int first_pair, int count, int32_t *mf
  *           sequential float64 normal-equation sums (motion.py:232-279)
  *           -> sums_out[P][15] = F (9, row-major) | Sx (3) | Sy (3)
  * `procedure` / `search_window` select the BBME used at levels 1 and 2 (the reference
- * hard-codes diamond, GME_SEARCH_DIAMOND; exhaustive serves BASELINE config 4). */
+ * hard-codes diamond, GME_SEARCH_DIAMOND; exhaustive serves BASELINE config 4).
+ * The level searches are launched so that the caller's work between the stages overlaps them:
+ * begin returns once the first parameters are on the host with the level-1 search already
+ * running; fit(level 1) returns its sums with the level-2 search running.  New frame data
+ * (upload / synth / invalidate) ends a staged run: fit then reports GME_ERR_STATE until begin. */
 GME_API int gme_seq_gme_begin(gme_seq *seq, int frame_distance, int bbme_block_size, int procedure,
                       int search_window, float *params0_out);
 GME_API int gme_seq_gme_fit(gme_seq *seq, int level, const double *params_in, double outlier_fraction,
