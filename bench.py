@@ -106,7 +106,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=512, help="frame pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="frame pairs per step per GPU (default 512; 2048 for the gme* configs, whose host-side "
+                         "solves between device stages cost the same per step whatever the batch)")
     ap.add_argument("--config", default="exh720", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,29 +157,36 @@ def main():
 
     import _gme_native as native
     ctx = native.Context(local)
-    B = args.pairs
+    B = args.pairs if args.pairs is not None else (2048 if proc in (-1, -2) else 512)
+    gme = proc < 0
+    # GME runs cut the resident pairs into `streams` ranges, each on its own HIP stream and host
+    # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "3"))
+    shard = None
     if proc == -3:
         import sequence
         n_frames = int(os.environ.get("GME_BENCH_FRAMES", "2000"))
-        shard = sequence.ShardedSequence(H, W, n_frames, 1, rank=rank, world=world, ctx=ctx)
+        shard = sequence.ShardedSequence(H, W, n_frames, 1, rank=rank, world=world, ctx=ctx, streams=streams)
         shard.synth(seed)                          # each rank generates its own slice (pairs + 1 halo frame)
-        seq = shard.seq
         B = shard.n_pairs                          # pairs of THIS rank; the step covers the whole sequence
+    elif gme:
+        import sequence
+        shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams)
+        shard.synth(seed, rank * B)                # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
     else:
         seq = native.Sequence(ctx, B + 1, H, W)
-        seq.synth(seed, rank * B)                  # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
+        seq.synth(seed, rank * B)
+    if shard is not None:
+        shard.sync()
     ctx.sync()
 
-    gme = proc < 0
     if proc == -3:
-        import motion
         last = {}
         gather_dev = torch.device("cuda", local) if (dist is not None and dist.get_backend() == "nccl") else None
 
         def step():
-            seq.invalidate_pyramids()
-            params = shard.estimate()
-            psnr = shard.compensate(params)
+            shard.invalidate()
+            params, psnr = shard.estimate_and_compensate()
             rows = np.concatenate([params, psnr[:, None]], axis=1)
             if dist is not None:                   # the path's one exchange: 56 B per pair over RCCL
                 rows = sequence.gather_parameters(rows, shard.n_pairs_total, rank, dist.get_world_size(), gather_dev)
@@ -189,9 +198,11 @@ def main():
         def step():
             # motion.global_motion_estimation + results.py:52-59,109 for every resident pair;
             # frames change between videos, so the pyramids are rebuilt inside the step
-            seq.invalidate_pyramids()
-            params = motion.estimate_sequence(seq, 1, 0, sw) if proc == -2 else motion.estimate_sequence(seq, 1)
-            last["params"], last["sse"] = params, seq.compensate(1, int(motion.BBME_BLOCK_SIZE), params)
+            shard.invalidate()
+            if proc == -2:
+                last["params"], last["psnr"] = shard.estimate_and_compensate(0, sw)
+            else:
+                last["params"], last["psnr"] = shard.estimate_and_compensate()
     else:
         def step():
             # per-frame auxiliary tables (box sums for the pruning bound / the MSE identity) are
@@ -201,6 +212,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if shard is not None:
+        shard.sync()
     ctx.sync()
     barrier()
     ctx.timer_start()
@@ -208,9 +221,13 @@ def main():
     for _ in range(args.steps):
         step()
     kernel_ms = ctx.timer_stop() / max(args.steps, 1)      # HIP events on the launch stream; synchronises
+    if shard is not None:
+        shard.sync()
     ctx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    if gme:
+        kernel_ms = 1e3 * elapsed / max(args.steps, 1)     # several streams: the whole step on the wall clock
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -226,7 +243,7 @@ def main():
     if rank == 0 and args.config == "gme720":
         g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_gme.npz"))
         import hashlib
-        comp_sha = hashlib.sha256(seq.read_compensated(0).tobytes()).hexdigest()
+        comp_sha = hashlib.sha256(shard.read_compensated(0).tobytes()).hexdigest()
         parity = bool(np.allclose(last["params"][0], g4["synth720_params"], rtol=1e-10, atol=1e-12)
                       and comp_sha == str(g4["synth720_comp_sha"]))
 
@@ -248,7 +265,8 @@ def main():
             "scaling": "strong" if proc == -3 else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
-                       "sharding": "frame pairs across ranks, no data-path collective"},
+                       "sharding": "frame pairs across ranks, no data-path collective",
+                       "streams_per_gpu": len(shard.lanes) if shard is not None else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_exh_sea16p<3, 6>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else

@@ -59,10 +59,24 @@ def gather_parameters(local, n_pairs, rank, world, device=None):
     return np.concatenate(rows, axis=0)
 
 
-class ShardedSequence:
-    """This rank's slice of a video: frames in HBM, pair-level results on demand."""
+class _Lane:
+    """One stream's part of a shard: its own context (HIP stream) and resident frames."""
 
-    def __init__(self, height, width, n_frames, frame_distance=1, rank=0, world=1, ctx=None):
+    def __init__(self, ctx, seq, lo, hi):
+        self.ctx, self.seq, self.lo, self.hi = ctx, seq, lo, hi    # local pair range [lo, hi)
+
+
+class ShardedSequence:
+    """This rank's slice of a video: frames in HBM, pair-level results on demand.
+
+    ``streams`` > 1 cuts the slice once more into that many contiguous pair ranges, each with
+    its own context (= HIP stream) on the same GPU and driven by its own host thread.  The
+    staged estimate (motion.estimate_sequence) has the host solve 3x3 systems between device
+    stages; with several streams one range's solves and launch latencies are covered by the
+    other ranges' kernels.  Results do not depend on ``streams``.
+    """
+
+    def __init__(self, height, width, n_frames, frame_distance=1, rank=0, world=1, ctx=None, streams=1):
         self.ctx = ctx or _native.default_context()
         self.H, self.W, self.fd = int(height), int(width), int(frame_distance)
         self.n_frames_total = int(n_frames)
@@ -70,48 +84,118 @@ class ShardedSequence:
         self.rank, self.world = rank, world
         self.pair_start, self.pair_stop = shard_range(self.n_pairs_total, rank, world)
         self.first_frame, n_local = shard_frames(self.n_pairs_total, self.fd, rank, world)
-        self.seq = _native.Sequence(self.ctx, max(n_local, self.fd + 1), self.H, self.W) if n_local else None
+        self.lanes = []
+        n_loc = self.pair_stop - self.pair_start
+        k = max(1, min(int(streams), n_loc))
+        for j in range(k if n_local else 0):
+            lo, hi = shard_range(n_loc, j, k)
+            c = self.ctx if j == 0 else _native.Context(self.ctx.device)
+            n_fr = (hi - lo) + self.fd if k > 1 else max(n_local, self.fd + 1)
+            self.lanes.append(_Lane(c, _native.Sequence(c, n_fr, self.H, self.W), lo, hi))
+        self.seq = self.lanes[0].seq if len(self.lanes) == 1 else None     # single-stream shards: the sequence itself
+        self._pool = None
 
     @property
     def n_pairs(self):
         return self.pair_stop - self.pair_start
 
+    def _each(self, fn):
+        """fn(lane) for every lane, one host thread per lane; results in lane order."""
+        if len(self.lanes) <= 1:
+            return [fn(lane) for lane in self.lanes]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(len(self.lanes))
+        return list(self._pool.map(fn, self.lanes))
+
+    def _lane_of(self, pair):
+        for lane in self.lanes:
+            if lane.lo <= pair < lane.hi:
+                return lane, pair - lane.lo
+        raise IndexError("pair %d is not in this shard" % pair)
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
+        for lane in self.lanes:
+            lane.seq.close()
+            if lane.ctx is not self.ctx:
+                lane.ctx.close()
+        self.lanes, self.seq = [], None
+
+    def sync(self):
+        for lane in self.lanes:
+            lane.ctx.sync()
+
+    def invalidate(self):
+        """Mark everything derived from the frames stale (new video in the same buffers)."""
+        for lane in self.lanes:
+            lane.seq.invalidate_pyramids()
+
     def load(self, frames):
         """`frames` is the WHOLE video (uint8[N, H, W] or a list); only this rank's slice is uploaded."""
-        if self.seq is None:
-            return
-        for k in range(self.seq.N):
-            self.seq.upload(k, np.ascontiguousarray(frames[self.first_frame + k], dtype=np.uint8)[None])
+        for lane in self.lanes:
+            for k in range(lane.seq.N):
+                g = self.first_frame + lane.lo + k
+                if g < len(frames):
+                    lane.seq.upload(k, np.ascontiguousarray(frames[g], dtype=np.uint8)[None])
 
-    def synth(self, seed):
-        """Generate this rank's slice of the synthetic sequence `seed` on its own GPU."""
-        if self.seq is not None:
-            self.seq.synth(seed, self.first_frame)
+    def synth(self, seed, t0=0):
+        """Generate this rank's slice of the synthetic sequence `seed` (video frame k = time t0 + k) on its own GPU."""
+        for lane in self.lanes:
+            lane.seq.synth(seed, t0 + self.first_frame + lane.lo)
 
     def motion_fields(self, block_size, search_window, procedure, pnorm):
         """bbme.get_motion_field for every local pair -> int32[P_local, h, w, 2]."""
-        if self.seq is None:
+        if not self.lanes:
             return np.zeros((0, int(self.H / block_size), int(self.W / block_size), 2), np.int32)
-        self.seq.bbme(self.fd, block_size, search_window, procedure, pnorm)
-        return self.seq.read_mv()
 
-    def estimate(self):
+        def run(lane):
+            lane.seq.bbme(self.fd, block_size, search_window, procedure, pnorm)
+            return lane.seq.read_mv(0, lane.hi - lane.lo)
+        return np.concatenate(self._each(run), axis=0)
+
+    def estimate(self, procedure=3, search_window=2):
         """motion.global_motion_estimation for every local pair -> float64[P_local, 6]."""
-        if self.seq is None:
+        if not self.lanes:
             return np.zeros((0, 6))
-        return motion.estimate_sequence(self.seq, self.fd)
+        return np.concatenate(self._each(
+            lambda lane: motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:lane.hi - lane.lo]), axis=0)
+
+    def _psnr(self, sse):
+        """utils.PSNR (utils.py:100-116) from sums of squared error: -1 where the frames are equal,
+        else 20 log10(255 / sqrt(mse)) -- the real part of the reference's complex value."""
+        mse = np.asarray(sse, dtype=np.float64) / (self.H * self.W)
+        out = np.full(len(mse), -1.0)
+        nz = mse != 0
+        out[nz] = 20.0 * np.log10(255.0 / np.sqrt(mse[nz]))
+        return out
 
     def compensate(self, params):
         """results.py:52-59,109 for every local pair -> PSNR(current, compensated) as float64[P_local]."""
-        if self.seq is None:
+        if not self.lanes:
             return np.zeros(0)
-        from cmath import log10, sqrt
-        sse = self.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE), params)
-        out = np.empty(len(sse))
-        for k, s in enumerate(sse):
-            mse = int(s) / (self.H * self.W)
-            out[k] = -1 if mse == 0 else (20 * log10(255.0 / sqrt(mse))).real
-        return out
+        params = np.asarray(params, dtype=np.float64)
+        sse = self._each(lambda lane: lane.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE),
+                                                          params[lane.lo:lane.hi])[:lane.hi - lane.lo])
+        return self._psnr(np.concatenate(sse))
+
+    def estimate_and_compensate(self, procedure=3, search_window=2):
+        """estimate() then compensate() per stream without a join in between -> (params[P,6], psnr[P])."""
+        if not self.lanes:
+            return np.zeros((0, 6)), np.zeros(0)
+
+        def run(lane):
+            n = lane.hi - lane.lo
+            p = motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:n]
+            return p, lane.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE), p)[:n]
+        parts = self._each(run)
+        return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]))
+
+    def read_compensated(self, pair):
+        lane, k = self._lane_of(pair)
+        return lane.seq.read_compensated(k)
 
     def gather(self, local_rows, device=None):
         return gather_parameters(local_rows, self.n_pairs_total, self.rank, self.world, device)

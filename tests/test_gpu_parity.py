@@ -299,10 +299,20 @@ def test_sequence_batch_matches_reference_flow(golden, mods):
             np.testing.assert_allclose(params[p], g[k + "params"], rtol=1e-10, atol=1e-12)
             assert np.array_equal(sh.seq.read_compensated(p), g[k + "comp"]), k
             assert abs(psnr[p] - float(g[k + "psnr"])) < 1e-9
-    # two virtual ranks on one device reproduce the single-rank answer
     whole = sequence.ShardedSequence(128, 192, 6, 1)
     whole.load(frames)
     want = whole.estimate()
+    want_psnr = whole.compensate(want)
+    # several streams per GPU (one host thread each) change nothing but the schedule
+    multi = sequence.ShardedSequence(128, 192, 6, 1, streams=3)
+    multi.load(frames)
+    assert len(multi.lanes) == 3 and multi.seq is None
+    mp, mpsnr = multi.estimate_and_compensate()
+    assert np.array_equal(mp, want) and np.array_equal(mpsnr, want_psnr)
+    assert np.array_equal(multi.read_compensated(4), whole.seq.read_compensated(4))
+    assert np.array_equal(multi.motion_fields(16, 8, 0, 0), whole.motion_fields(16, 8, 0, 0))
+    multi.close()
+    # two virtual ranks on one device reproduce the single-rank answer
     parts = []
     for r in range(2):
         sh = sequence.ShardedSequence(128, 192, 6, 1, rank=r, world=2)
