@@ -373,6 +373,90 @@ __global__ void __launch_bounds__(256) k_compensate(const uint8_t* frames, long 
     }
 }
 
+// Fast form for block sizes that are multiples of 16 on frames whose width is a multiple of 16
+// (the GME pipeline: bs = 16 at 720x480 and 1920x1080): a thread owns 16 horizontally adjacent
+// pixels -- one block column, so one vector -- of two rows 16 apart; the source run is fetched as
+// five aligned dwords + four v_alignbyte, stored as one 16-byte vector, and the squared error
+// against `cur` is three v_dot4_u32_u8 per dword (sum c^2 + sum v^2 - 2 sum c.v).  The untouched
+// original is only read where the rule of motion.py:309-318 keeps it (source outside the frame,
+// rows/columns beyond the field).  Workgroup tile: 256 x 32 pixels, one atomic.
+__global__ void __launch_bounds__(256) k_compensate16(const uint8_t* frames, long long frame_stride, int H, int W,
+                                                       int pitch, const int32_t* mf32, const double* params, int h,
+                                                       int w, uint8_t* out, long long out_stride, int out_pitch,
+                                                       const uint8_t* cur, long long cur_stride,
+                                                       unsigned long long* sse)
+{
+    __shared__ unsigned part[4];
+    const int pair = blockIdx.z;
+    const int x = (blockIdx.x * 16 + (threadIdx.x & 15)) * 16;
+    const int y0 = blockIdx.y * 32 + (threadIdx.x >> 4);
+    const uint8_t* f = frames + (long long)pair * frame_stride;
+    const int bs = H / h;                               // height only, motion.py:303
+    unsigned err = 0;
+    if (x < W) {
+        const int j = x / bs;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int y = y0 + 16 * half;
+            if (y >= H) break;
+            const int i = y / bs;
+            uint4 v;
+            bool have = false;
+            if (i < h && j < w) {
+                int d0, d1;
+                if (mf32) {
+                    const int32_t* m = mf32 + (((long long)pair * h + i) * w + j) * 2;
+                    d0 = m[0]; d1 = m[1];
+                } else {
+                    const double* p = params + (long long)pair * 6;
+                    d0 = model_component(p[0], p[1], p[2], i, j);
+                    d1 = model_component(p[3], p[4], p[5], i, j);
+                }
+                const long long sy = (long long)y - d1, sx = (long long)x - d0;
+                if (sy >= 0 && sy < H) {
+                    if (sx >= 0 && sx + 16 <= W) {
+                        const uint32_t* sp = (const uint32_t*)(f + sy * pitch + (sx & ~3ll));
+                        const uint32_t sh = (uint32_t)sx & 3u;
+                        const uint32_t t0 = sp[0], t1 = sp[1], t2 = sp[2], t3 = sp[3];
+                        const uint32_t t4 = sh ? sp[4] : 0u;        // sp[4] may lie past the row when sx + 16 == pitch
+                        v.x = __builtin_amdgcn_alignbyte(t1, t0, sh); v.y = __builtin_amdgcn_alignbyte(t2, t1, sh);
+                        v.z = __builtin_amdgcn_alignbyte(t3, t2, sh); v.w = __builtin_amdgcn_alignbyte(t4, t3, sh);
+                        have = true;
+                    } else if (sx > -16 && sx < W) {            // straddles the left/right frame edge: per pixel
+                        v = *(const uint4*)(f + (long long)y * pitch + x);
+                        uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+                        for (int q = 0; q < 16; ++q)
+                            if (sx + q >= 0 && sx + q < W)
+                                vv[q >> 2] = (vv[q >> 2] & ~(0xFFu << (8 * (q & 3)))) | ((uint32_t)f[sy * pitch + sx + q] << (8 * (q & 3)));
+                        v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+                        have = true;
+                    }
+                }
+            }
+            if (!have) v = *(const uint4*)(f + (long long)y * pitch + x);
+            *(uint4*)(out + (long long)pair * out_stride + (long long)y * out_pitch + x) = v;
+            if (cur) {
+                const uint4 c = *(const uint4*)(cur + (long long)pair * cur_stride + (long long)y * pitch + x);
+                const uint32_t cc[4] = { c.x, c.y, c.z, c.w }, vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned s2 = __builtin_amdgcn_udot4(cc[q], cc[q], __builtin_amdgcn_udot4(vv[q], vv[q], 0u, false), false);
+                    err += s2 - 2u * __builtin_amdgcn_udot4(cc[q], vv[q], 0u, false);
+                }
+            }
+        }
+    }
+    if (sse) {                                          // integer sums: order independent, deterministic
+        for (int m = 32; m > 0; m >>= 1) err += (unsigned)__shfl_xor((int)err, m, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = err;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+            if (t) atomicAdd(&sse[pair], t);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sse(const uint8_t* a, long long a_stride, int a_pitch, const uint8_t* b,
                                               long long b_stride, int b_pitch, int H, int W,
                                               unsigned long long* sse)
@@ -451,6 +535,14 @@ int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride,
     if (pairs == 0) return GME_OK;
     if (sse) GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
     const dim3 grid((W + 255) / 256, (H + COMP_ROWS - 1) / COMP_ROWS, pairs);
+    if (h > 0 && (H / h) % 16 == 0 && W % 16 == 0 && pitch % 16 == 0 && out_pitch % 16 == 0 && frame_stride % 16 == 0 &&
+        out_stride % 16 == 0 && (!cur || cur_stride % 16 == 0) &&
+        (((uintptr_t)frames | (uintptr_t)out | (uintptr_t)cur) & 15) == 0 && !getenv("GME_FORCE_GENERIC")) {
+        hipLaunchKernelGGL(k_compensate16, grid, dim3(256), 0, ctx->stream, frames, (long long)frame_stride, H, W, pitch,
+                           mf32, params, h, w, out, (long long)out_stride, out_pitch, cur, (long long)cur_stride, sse);
+        GME_HIP_TRY(hipGetLastError());
+        return GME_OK;
+    }
     hipLaunchKernelGGL(k_compensate, grid, dim3(256), 0, ctx->stream, frames, (long long)frame_stride, H, W, pitch,
                        mf32, params, h, w, out, (long long)out_stride, out_pitch, cur, (long long)cur_stride, sse);
     GME_HIP_TRY(hipGetLastError());

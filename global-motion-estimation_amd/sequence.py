@@ -163,11 +163,21 @@ class ShardedSequence:
         return np.concatenate(self._each(
             lambda lane: motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:lane.hi - lane.lo]), axis=0)
 
-    def _psnr(self, sse):
+    def _psnr(self, sse, exact=True):
         """utils.PSNR (utils.py:100-116) from sums of squared error: -1 where the frames are equal,
-        else 20 log10(255 / sqrt(mse)) -- the real part of the reference's complex value."""
+        else the real part of the reference's complex 20 log10(255 / sqrt(mse)).
+
+        ``exact`` evaluates it per pair with cmath like the reference (results.py writes
+        ``str(value)`` into psnr_records.json, so the last bit shows); the vectorised NumPy form
+        differs from it by at most 2e-14 dB and is what the batch hot path uses."""
         mse = np.asarray(sse, dtype=np.float64) / (self.H * self.W)
         out = np.full(len(mse), -1.0)
+        if exact:
+            from cmath import log10, sqrt
+            for k, m in enumerate(mse):
+                if m != 0:
+                    out[k] = (20 * log10(255.0 / sqrt(m))).real
+            return out
         nz = mse != 0
         out[nz] = 20.0 * np.log10(255.0 / np.sqrt(mse[nz]))
         return out
@@ -181,7 +191,7 @@ class ShardedSequence:
                                                           params[lane.lo:lane.hi])[:lane.hi - lane.lo])
         return self._psnr(np.concatenate(sse))
 
-    def estimate_and_compensate(self, procedure=3, search_window=2):
+    def estimate_and_compensate(self, procedure=3, search_window=2, exact_psnr=False):
         """estimate() then compensate() per stream without a join in between -> (params[P,6], psnr[P])."""
         if not self.lanes:
             return np.zeros((0, 6)), np.zeros(0)
@@ -191,7 +201,7 @@ class ShardedSequence:
             p = motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:n]
             return p, lane.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE), p)[:n]
         parts = self._each(run)
-        return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]))
+        return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]), exact_psnr)
 
     def read_compensated(self, pair):
         lane, k = self._lane_of(pair)

@@ -259,6 +259,46 @@ def test_affine_compensate_psnr_edges(golden, mods):
         assert np.array_equal(motion.compute_first_parameters(g["fp_in_%d" % k]), g["fp_out_%d" % k])
 
 
+def test_compensate_fast_and_generic_kernels(mods, monkeypatch):
+    """k_compensate16 (16 pixels per thread; bs % 16 == 0 and W % 16 == 0) and the generic
+    k_compensate against the C oracle's motion.compensate_frame (motion.py:289-321): random
+    vectors up to +-60 px so that sources leave the frame on every side, rows/columns beyond the
+    field, bs 16 and 32, then the batched form with its fused squared error."""
+    native, _, motion, _ = mods
+    co = c_oracle()
+    rng = np.random.default_rng(77)
+    cases = []
+    for (H, W, bs) in ((96, 160, 16), (100, 176, 16), (480, 720, 16), (130, 256, 32), (70, 90, 16), (64, 64, 8)):
+        f = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        mf = rng.integers(-60, 61, (H // bs, W // bs, 2)).astype(np.int16)
+        mf[0, 0] = (0, 0)
+        cases.append((f, mf))
+        want = co.compensate(f, mf)
+        assert np.array_equal(motion.compensate_frame(f, mf), want), (H, W, bs)
+        fewer = mf[:-1, :-1] if mf.shape[0] > 2 and H % mf[:-1].shape[0] == 0 else mf
+        assert np.array_equal(motion.compensate_frame(f, fewer), co.compensate(f, fewer))
+    monkeypatch.setenv("GME_FORCE_GENERIC", "1")
+    for f, mf in cases:
+        assert np.array_equal(motion.compensate_frame(f, mf), co.compensate(f, mf))
+    monkeypatch.delenv("GME_FORCE_GENERIC")
+    # batched: model field from parameters + compensation + squared error, both kernels
+    ctx = native.default_context()
+    seq = native.Sequence(ctx, 4, 128, 192)
+    seq.synth(9, 0)
+    frames = [seq.read_frame(i) for i in range(4)]
+    params = np.array([[5.2, 0.11, -0.07, -3.4, 0.05, 0.2], [70.0, 0, 0, -90.0, 0, 0], [-0.4, 1.9, 0.0, 0.3, 0.0, -2.2]])
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GME_FORCE_GENERIC", env)
+        sse = seq.compensate(1, 16, params)
+        for p in range(3):
+            field = motion.get_motion_field_affine((8, 12), params[p])
+            want = co.compensate(frames[p], field)
+            assert np.array_equal(seq.read_compensated(p), want), (env, p)
+            assert int(sse[p]) == co.sse(frames[p + 1], want), (env, p)
+    seq.close()
+
+
 def test_degenerate_fits(golden, mods):
     """N < 4 blocks gives threshold index 0 and a singular system: LinAlgError as upstream."""
     _, _, motion, _ = mods
@@ -307,8 +347,9 @@ def test_sequence_batch_matches_reference_flow(golden, mods):
     multi = sequence.ShardedSequence(128, 192, 6, 1, streams=3)
     multi.load(frames)
     assert len(multi.lanes) == 3 and multi.seq is None
-    mp, mpsnr = multi.estimate_and_compensate()
+    mp, mpsnr = multi.estimate_and_compensate(exact_psnr=True)
     assert np.array_equal(mp, want) and np.array_equal(mpsnr, want_psnr)
+    assert np.abs(multi.estimate_and_compensate()[1] - want_psnr).max() < 1e-12
     assert np.array_equal(multi.read_compensated(4), whole.seq.read_compensated(4))
     assert np.array_equal(multi.motion_fields(16, 8, 0, 0), whole.motion_fields(16, 8, 0, 0))
     multi.close()
