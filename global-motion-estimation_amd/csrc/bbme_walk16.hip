@@ -239,13 +239,6 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };   // LDSP minus its centre
         int pr = r0, pc = c0;
         unsigned centre_cost;
-        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once
-            int cr[1] = { clamp_ref(pr, maxr) }, cc[1] = { clamp_ref(pc, maxc) };
-            bool ok[1] = { true };
-            unsigned cost[1];
-            EVAL8(1, cr, cc, ok, cost);
-            centre_cost = cost[0];
-        }
         // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns
         int my_dr = 0, my_dc = 0, my_sr = 0, my_sc = 0;
         const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
@@ -258,12 +251,18 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         // each 16-lane row plus four v_readlane.  Only a key whose cost is strictly below the centre's
         // moves the centre (bbme.py:507-510: first strict minimum, the centre is candidate 0); the
         // winner's offset comes out of nibble tables, so no per-candidate scalar position is needed.
-#define PATTERN_MIN(n, RRV, CCV, RMIN, RMAX, CMIN, CMAX, KMIN)                                        \
+#define PATTERN_MIN(n, SPAN, RRV, CCV, KMIN)                                                          \
     do {                                                                                             \
-        if (!(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 &&         \
-              (CMAX) <= wc0 + WIN_SPAN)) {                                                           \
-            wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                                  \
-            wc0 = ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3;                            \
+        /* every candidate is clamp(centre + d), |d| <= SPAN, and the clamp is 1-Lipschitz, so the    \
+           pattern lies within SPAN of the clamped centre: two unsigned range tests decide whether \
+           the window still holds it (conservative: a miss only costs a re-stage) */               \
+        const int prc_ = clamp_ref(pr, maxr), pcc_ = clamp_ref(pc, maxc);                            \
+        if (!(have_win && (unsigned)(prc_ - (SPAN) - wr0) <= (unsigned)(WIN_ROWS - 16 - 2 * (SPAN)) && \
+              (unsigned)(pcc_ - (SPAN) - wc0) <= (unsigned)(WIN_SPAN - 2 * (SPAN)))) {               \
+            const int rmin_ = clamp_ref(pr - (SPAN), maxr), rmax_ = clamp_ref(pr + (SPAN), maxr);    \
+            const int cmin_ = clamp_ref(pc - (SPAN), maxc), cmax_ = clamp_ref(pc + (SPAN), maxc);    \
+            wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                     \
+            wc0 = (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3;                               \
             stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
             have_win = true;                                                                         \
         }                                                                                            \
@@ -274,12 +273,17 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         const unsigned k2_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 32), k3_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 48); \
         KMIN = min(min(k0_, k1_), min(k2_, k3_));                                                    \
     } while (0)
+        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once
+            const int rr0 = clamp_ref(pr, maxr), cc0 = clamp_ref(pc, maxc);
+            unsigned k0;
+            PATTERN_MIN(1, 0, rr0, cc0, k0);
+            centre_cost = k0 >> 3;
+        }
         int it = 0;
         for (;;) {
             const int rrv = clamp_ref(pr + my_dr, maxr), ccv = clamp_ref(pc + my_dc, maxc);
             unsigned kmin;
-            PATTERN_MIN(8, rrv, ccv, clamp_ref(pr - 2, maxr), clamp_ref(pr + 2, maxr), clamp_ref(pc - 2, maxc),
-                        clamp_ref(pc + 2, maxc), kmin);
+            PATTERN_MIN(8, 2, rrv, ccv, kmin);
             // candidate 0 of the pattern is the clamped centre itself
             int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
             if ((kmin >> 3) < centre_cost) {
@@ -299,8 +303,7 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
             int br = pr, bc = pc;
             const int rrv = clamp_ref(pr + my_sr, maxr), ccv = clamp_ref(pc + my_sc, maxc);
             unsigned kmin;
-            PATTERN_MIN(4, rrv, ccv, clamp_ref(pr - 1, maxr), clamp_ref(pr + 1, maxr), clamp_ref(pc - 1, maxc),
-                        clamp_ref(pc + 1, maxc), kmin);
+            PATTERN_MIN(4, 1, rrv, ccv, kmin);
             if ((kmin >> 3) < centre_cost) {
                 const unsigned k = kmin & 3u;
                 // sdr + 1 = 1,2,1,0 and sdc + 1 = 2,1,0,1 as nibbles

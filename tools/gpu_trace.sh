@@ -16,7 +16,7 @@ PY
 if [ -n "$PMC" ]; then
 for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-30)
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 "${@:5}" > $OUT/pmc_$N.log 2>&1 || echo "pmc $C failed"
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $ROOT/bench.py --no-cpu-baseline "$@" --steps 3 --warmup 1 > $OUT/pmc_$N.log 2>&1 || echo "pmc $C failed"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT "$PMC"
 fi
