@@ -403,7 +403,8 @@ def test_sea_schedules_agree(mods, monkeypatch, mode):
     monkeypatch.setenv("GME_SEA_PERSIST", mode)
     ctx = native.default_context()
     co = c_oracle()
-    for (n, h, w, sw, seed) in ((12, 96, 176, 16, 3), (4, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6)):
+    for (n, h, w, sw, seed) in ((12, 96, 176, 16, 3), (4, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6),
+                                (5, 80, 112, 24, 7), (9, 48, 80, 0, 8)):
         seq = native.Sequence(ctx, n, h, w)
         seq.synth(seed, 0)
         frames = [seq.read_frame(i) for i in range(n)]
