@@ -7,7 +7,9 @@
 // minimum: it can neither win nor tie, so skipping it keeps the reference's "first strict
 // minimum in scan order" result bit for bit.
 //
-// Per workgroup (NB adjacent macroblocks, one wave each, as in k_exh_qsad16):
+// Two kernels run the same phases: k_exh_sea16 (one tile per workgroup) and k_exh_sea16p (persistent
+// workgroups that prefetch the next tile into registers, bbme_sea_common.h: persistent_tiles).
+// Per tile (NB adjacent macroblocks, one wave each, as in k_exh_qsad16):
 //   A  stage the search window of `cur` and the anchors in LDS; quadrant sums of each anchor;
 //   A' 8x8 box sums S8 of the staged window, in LDS, two separable passes: the horizontal one is
 //      two v_qsad_pk_u16_u8 against a zero reference (four sliding 8-byte sums per lane-op), the
@@ -19,9 +21,9 @@
 //   E  the list is processed 64*NB patches at a time, one patch per lane (R x 16 x 4
 //      v_qsad_pk_u16_u8 against the anchor read from LDS -- lanes of one wave may serve different
 //      blocks), best keys merged with LDS atomicMin; before each chunk entries whose LB exceeds
-//      the tightened UB are dropped;
+//      the tightened UB are dropped; template flag E4: four lanes per patch (large windows);
 //   F  lane 0 of each wave stores its block's vector.
-// On the synthetic and the reference's doc frames 3-6 % of the patches survive.
+// On the synthetic and the reference's doc frames 2-6 % of the patches survive.
 #include "bbme_sea_common.h"
 
 namespace {
@@ -94,7 +96,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
     const bool wave_ok = bcol < d.nbc;                     // ragged last workgroup of a block row
     const int c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
-    (void)NB; (void)T;
+    (void)NB;
 
     // ---- A': 8x8 box sums of the window (bbme_sea_common.h) ------------------------------------
     box_sums8<R>(d, win, s8, tid);

@@ -3,11 +3,13 @@
 //
 //   k_walk16<PNORM>   bs = 16: one wavefront per macroblock.  The wave is cut into 8 groups
 //                     of 8 lanes; a group evaluates one candidate per round, each lane owning
-//                     two 16-byte rows of the block (two unaligned 16-byte loads of `cur`,
-//                     8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8 anchor dwords kept in VGPRs),
-//                     followed by a 3-step xor reduction inside the group.  Up to 8 candidates
-//                     cost one round; the centre of a pattern is usually the previous winner,
-//                     whose cost is carried instead of recomputed.
+//                     two 16-byte rows of the block (ten dwords of the per-wave LDS window of
+//                     `cur`, 8 v_alignbyte_b32, 8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8
+//                     anchor dwords kept in VGPRs), followed by a 3-step DPP reduction inside
+//                     the group.  Up to 8 candidates cost one round; the centre of a pattern is
+//                     the previous winner, whose cost is carried instead of recomputed.  Diamond
+//                     rounds pick the winner in the vector unit (PATTERN_MIN); three-step and
+//                     2-D log keep wave-uniform candidate arrays (EVAL8).
 //   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
 //                     coarsest pyramid level, 5400 blocks per 720x480 pair).
 //
@@ -124,7 +126,7 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
     if (valid) {
         const int bc = cc - wc0;
         const uint32_t sh = (uint32_t)bc & 3u;
-        const uint32_t* p = lds + (rr - wr0 + lrow) * WIN_PITCH + (bc >> 2);
+        const uint32_t* p = lds + __mul24(rr - wr0 + lrow, WIN_PITCH) + (bc >> 2);    // row < 40: 24-bit multiply (v_mul_lo_u32 is quarter rate)
         uint32_t l0[5], l1[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[WIN_PITCH + j]; }
@@ -209,24 +211,6 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (grp == k_) { rr_ = CR[k_]; cc_ = CC[k_]; ok_ = OK[k_]; } \
         const unsigned c_ = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, wr0, wc0, rr_, cc_, ok_, lrow)  \
                                     : group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);     \
-        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
-    } while (0)
-
-    // Diamond rounds: every lane knows its own pattern offset, so the candidate position is two
-    // vector adds + clamps instead of an 8-way select of wave-uniform arrays; the bounding box of
-    // the (clamped) pattern is scalar arithmetic.
-#define EVALP(n, RRV, CCV, RMIN, RMAX, CMIN, CMAX, COST)                                              \
-    do {                                                                                             \
-        bool lds_ok_ = true;                                                                         \
-        if (!(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 &&         \
-              (CMAX) <= wc0 + WIN_SPAN)) {                                                           \
-            wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                                  \
-            wc0 = ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3;                            \
-            stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
-            have_win = true;                                                                         \
-        }                                                                                            \
-        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, wr0, wc0, RRV, CCV, grp < (n), lrow);  \
-        (void)lds_ok_;                                                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
     } while (0)
 
@@ -374,7 +358,6 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         out1 = br - r0; out0 = bc - c0;
     }
 #undef EVAL8
-#undef EVALP
     if (lane == 0) {
         if (overrun) atomicExch(d.status, 1);
         int32_t* o = d.mf + gid * 2;
