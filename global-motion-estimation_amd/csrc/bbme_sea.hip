@@ -78,23 +78,23 @@ __device__ __forceinline__ void lower_bounds(const uint64_t* sp0, int XQ, int pr
 // Phases A' .. F of one tile.  On entry the window and the anchors are staged, *count == 0 and the
 // workgroup has passed a barrier; there is no barrier after F.
 template <int R, bool E4>
-__device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+__device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                             uint32_t mine, uint32_t a01, uint32_t a23, int tid)
 {
     const int NB = d.nb, T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
     uint32_t* win = lds + L.win;                           // [win_rows][pitch_dw]
-    uint32_t* anchor = lds + L.anchor;                     // [NB][64]
+    uint32_t* anchor = lds + L.anchor;                     // [NB][ANCHOR_STRIDE]
     uint32_t* best = lds + L.best;                         // [NB] keys, 8 bytes apart (low dword used here)
     uint32_t* count = lds + L.count;
-    uint64_t* s8 = (uint64_t*)(lds + L.s8);                // [16R+8][XQ] packed u16 x 4: S8(y, 4s .. 4s+3)
+    uint64_t* s8 = (uint64_t*)(lds + L.s8);                // [s8_rows][XQ] packed u16 x 4: S8(y, 4s .. 4s+3)
     uint32_t* work = lds + L.work;                         // [NB*64*R] entries: wave<<25 | lane<<19 | k<<16 | LB
-    const int r0 = brow * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int bcol = bcol0 + wave;
-    const bool wave_ok = bcol < d.nbc;                     // ragged last workgroup of a block row
-    const int c0 = bcol * 16;
+    const WaveBlock wb = wave_block(d, trow, bcol0, wave);
+    const int brow = wb.brow, bcol = wb.bcol;
+    const bool wave_ok = wb.ok;                            // ragged last tile of a block row / column
+    const int r0 = brow * 16, c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
     (void)NB;
 
@@ -116,7 +116,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
         // per patch k: min over its candidates of (LB << 13) + local, local = (4k+e)*R + i (any
         // consistent index will do here: the bound only has to name one good candidate)
         uint32_t pkey[R];
-        const uint64_t* sp0 = s8 + (prow * R) * XQ + wave * 4 + q * R;
+        const uint64_t* sp0 = s8 + (16 * wb.wr + prow * R) * XQ + wb.wc * 4 + q * R;
         if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
             lower_bounds<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
         else
@@ -141,8 +141,8 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             for (int which = 0; which < 2; ++which) {
                 const int idx = which ? idx1 : idx0;
                 const int ci = idx / NC, ri = idx - ci * NC;
-                const int byte = wave * 16 + ci + 4 * aj;
-                const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
+                const int byte = wb.wc * 16 + ci + 4 * aj;
+                const uint32_t* p = win + (16 * wb.wr + ri + arow) * d.pitch_dw + (byte >> 2);
                 const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
                 packed += __builtin_amdgcn_sad_u8(v, mine, 0u) << (16 * which);
             }
@@ -179,12 +179,13 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             }
             // the quad is uniform in `active` (same entry), so the DPP exchange below is safe
             const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+            const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
             const int prow2 = l2 >> 2, q2 = l2 & 3;
             uint64_t acc[R];
     #pragma unroll
             for (int i = 0; i < R; ++i) acc[i] = 0;
             if (active) {
-                const uint32_t* lrow = win + (prow2 * R + 4 * sub) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+                const uint32_t* lrow = win + (16 * wr2 + prow2 * R + 4 * sub) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
                 const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + 16 * sub;
     #pragma unroll
                 for (int t = 0; t < R + 3; ++t) {
@@ -217,11 +218,13 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
                 acc[i] = ((uint64_t)hi << 32) | lo;
             }
             if (active && sub == 0) {
-                const int c02 = (bcol0 + w2) * 16;
+                const int c02 = (bcol0 + wc2) * 16, r02 = (trow * d.tr + wr2) * 16;
                 const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                const int lo_r2 = max(0, d.sw - r02), hi_r2 = min(NC - 1, d.H - 16 - r02 + d.sw);
+                const bool rows_inside2 = NC == 16 * R && lo_r2 == 0 && hi_r2 == NC - 1;
                 const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
                 uint32_t key = 0xFFFFFFFFu;
-                if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+                if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
                     // whole window inside the frame: keys relative to the patch's first candidate, base added once
     #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4)
@@ -239,7 +242,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
     #pragma unroll
                         for (int i = 0; i < R; ++i) {
                             const int ri = ri0 + i;
-                            if (ri < lo_r || ri > hi_r) continue;
+                            if (ri < lo_r2 || ri > hi_r2) continue;
                             const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
                             key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
                         }
@@ -263,8 +266,9 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             }
             if (active) {
                 const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+            const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
                 const int prow2 = l2 >> 2, q2 = l2 & 3;
-                const uint32_t* lrow = win + (prow2 * R) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+                const uint32_t* lrow = win + (16 * wr2 + prow2 * R) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
                 const uint32_t* an = anchor + w2 * ANCHOR_STRIDE;
                 uint64_t acc[R];
     #pragma unroll
@@ -284,11 +288,13 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
                             acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], ar[j], acc[i]);
                     }
                 }
-                const int c02 = (bcol0 + w2) * 16;
+                const int c02 = (bcol0 + wc2) * 16, r02 = (trow * d.tr + wr2) * 16;
                 const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+                const int lo_r2 = max(0, d.sw - r02), hi_r2 = min(NC - 1, d.H - 16 - r02 + d.sw);
+                const bool rows_inside2 = NC == 16 * R && lo_r2 == 0 && hi_r2 == NC - 1;
                 const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
                 uint32_t key = 0xFFFFFFFFu;
-                if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+                if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
                     // whole window inside the frame: keys relative to the patch's first candidate, base added once
     #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4)
@@ -306,7 +312,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
     #pragma unroll
                         for (int i = 0; i < R; ++i) {
                             const int ri = ri0 + i;
-                            if (ri < lo_r || ri > hi_r) continue;
+                            if (ri < lo_r2 || ri > hi_r2) continue;
                             const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
                             key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
                         }
@@ -329,35 +335,6 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
     }
 }
 
-template <int R, bool E4>
-__global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
-{
-    extern __shared__ uint32_t lds[];
-    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
-    int pair, brow, bcol0;
-    if (!locate(d, &pair, &brow, &bcol0)) return;          // whole workgroup
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int NB = d.nb;
-    (void)NB;
-
-    STAMP(0);
-    // ---- A: window, anchor, quadrant sums ------------------------------------------------
-    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
-    uint32_t mine = 0, a01 = 0, a23 = 0;
-    if (bcol0 + wave < d.nbc) {
-        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
-        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
-        anchor_quadrants(mine, &a01, &a23);
-    }
-    if (threadIdx.x == 0) lds[L.count] = 0;
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
-    tile_phases<R, E4>(d, lds, L, pair, brow, bcol0, mine, a01, a23, (int)threadIdx.x);
-}
-
 // What the shared persistent driver (bbme_sea_common.h: persistent_tiles) needs from this kernel.
 template <int R, bool E4>
 struct MaeTile {
@@ -371,18 +348,47 @@ struct MaeTile {
         }
         return p;
     }
-    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                   uint32_t mine, const Pre& p, int tid)
     {
-        tile_phases<R, E4>(d, lds, L, pair, brow, bcol0, mine, p.a01, p.a23, tid);
+        tile_phases<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, tid);
     }
 };
+
+template <int R, bool E4>
+__global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
+{
+    extern __shared__ uint32_t lds[];
+    const Layout L = layout_of(d, R);
+    int pair, trow, bcol0;
+    if (!locate(d, &pair, &trow, &bcol0)) return;          // whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int NB = d.nb;
+    (void)NB;
+
+    STAMP(0);
+    // ---- A: window, anchor, quadrant sums ------------------------------------------------
+    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, trow * d.tr * 16);
+    uint32_t mine = 0;
+    const WaveBlock wb = wave_block(d, trow, bcol0, wave);
+    if (wb.ok) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(wb.brow * 16) * d.pitch + wb.bcol * 16;
+        mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+    }
+    const typename MaeTile<R, E4>::Pre pre = MaeTile<R, E4>::prep(d, lds, L, wave, lane, wb.ok, mine);
+    if (threadIdx.x == 0) lds[L.count] = 0;
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+    MaeTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
+}
 
 template <int R, int NV>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
-    persistent_tiles<NV, MaeTile<R, (R >= 4)>>(d, lds, make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq));
+    persistent_tiles<NV, MaeTile<R, (R >= 4)>>(d, lds, layout_of(d, R));
 }
 
 }  // namespace
@@ -415,15 +421,15 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.stamps = g_stamps;
 #endif
     size_t lds = 0;
-    GME_REQUIRE(plan(R, nbc, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
-    d.wg_per_pair = d.wg_per_row * nbr;
+    GME_REQUIRE(plan(R, nbr, nbc, job.sw, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
     d.sqbox = nullptr; d.sqbox_stride = 0;
-    d.magic_wpp = div_magic40(d.wg_per_pair);
-    d.magic_wpr = div_magic40(d.wg_per_row);
     const dim3 block(64 * d.nb);
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
-    if (pp.use) {
+    // R = 2, 3 with more than 8 staging rows per thread would spill the prefetched tile (64 VGPRs at
+    // 8 waves/SIMD); those shapes keep the one-tile kernel
+    const bool fits = R <= 1 || R >= 4 || nv <= 8;
+    if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
         d.tile_ctr = nullptr;
         if (pp.dynamic) {

@@ -1,19 +1,29 @@
 // Shared pieces of the successive-elimination exhaustive kernels (bbme_sea.hip: MAE,
 // bbme_sea_mse.hip: MSE): launch descriptor, LDS layout, window staging, 8x8 box sums.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gme_internal.h"
 
 namespace sea {
 
+// weight of window sharing in the tile-shape score (plan()); tuned by same-box sweeps
+#ifndef SEA_SHARE_WEIGHT
+#define SEA_SHARE_WEIGHT 0.5
+#endif
+
 struct SeaDev {
     const uint8_t* prev;
     const uint8_t* cur;
     long long plane_stride;
     int pairs, H, W, pitch, sw;
-    int nbr, nbc, nb, wg_per_row, wg_per_pair;
-    int pitch_dw, win_rows;
+    int nbr, nbc;
+    int tr, tc, nb;               // a tile is tr x tc macroblocks, one wave each: nb = tr * tc waves per workgroup
+    int wg_per_row, tile_rows, wg_per_pair;      // tiles per block row / tile rows / tiles per pair
+    uint32_t magic_tc;            // wave / tc (div_small)
+    int pitch_dw, win_rows;       // staged window: 16R + 15 + 16 (tr - 1) rows of pitch_dw dwords
+    int s8_rows;                  // rows of the box-sum table: 16R + 8 + 16 (tr - 1)
     int rstep;                    // staging: window rows covered by one sweep of the workgroup (T / pitch_dw)
     uint32_t magic_pitch;         // n / pitch_dw == (n * magic_pitch) >> 20 for n < 4096 (div_small)
     uint32_t magic_xq;            // same for n / xq
@@ -65,37 +75,22 @@ __device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(_
 // Workgroup -> (pair, block row, first block column).  Grid = (8 * wg_per_row, nbr, ceil(pairs / 8)):
 // workgroups go to the 8 XCDs round robin in x-fastest order, so the low 3 bits of blockIdx.x pick
 // the pair inside a group of 8 and all tiles of one pair land on one XCD (its L2 holds the pair).
-__device__ __forceinline__ bool locate(const SeaDev& d, int* pair, int* brow, int* bcol0)
+__device__ __forceinline__ bool locate(const SeaDev& d, int* pair, int* trow, int* bcol0)
 {
-#ifdef SEA_GRID1D
-    const int b = blockIdx.x;
-    *pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
-    const int wg = (b >> 3) % d.wg_per_pair;
-    *brow = wg / d.wg_per_row;
-    *bcol0 = (wg - *brow * d.wg_per_row) * d.nb;
-#else
     *pair = (int)blockIdx.z * 8 + (int)(blockIdx.x & 7);
-    *brow = (int)blockIdx.y;
-    *bcol0 = (int)(blockIdx.x >> 3) * d.nb;
-#endif
+    *trow = (int)blockIdx.y;
+    *bcol0 = (int)(blockIdx.x >> 3) * d.tc;
     return *pair < d.pairs;
 }
 
 inline bool grid_for(const SeaDev& d, dim3* grid)
 {
     const long long gz = ((long long)d.pairs + 7) / 8;
-#ifdef SEA_GRID1D
-    if (gz * 8 * d.wg_per_pair >= (1ll << 31)) return false;
-    *grid = dim3((unsigned)(gz * 8 * d.wg_per_pair));
-#else
-    if (gz > 65535 || d.nbr > 65535) return false;
-    *grid = dim3((unsigned)(8 * d.wg_per_row), (unsigned)d.nbr, (unsigned)gz);
-#endif
+    if (gz > 65535 || d.tile_rows > 65535) return false;
+    *grid = dim3((unsigned)(8 * d.wg_per_row), (unsigned)d.tile_rows, (unsigned)gz);
     return true;
 }
 
-// LDS carve-up shared by both kernels (dword offsets); `best` holds NB 64-bit slots so the MSE
-// kernel can keep 37-bit keys there (the MAE kernel uses the low dword of each).
 // Anchors sit 68 dwords apart, not 64: phase E lanes serving different blocks read the same anchor
 // element of "their" block at once, and a 64-dword stride would put all of those in one LDS bank.
 constexpr int ANCHOR_STRIDE = 68;
@@ -105,7 +100,7 @@ struct Layout {
     int win, anchor, best, count, a2, s8, work, total;
 };
 
-__host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq)
+__host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq, int s8_rows)
 {
     Layout l;
     l.win = 0;
@@ -113,10 +108,32 @@ __host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int p
     l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
     l.count = l.best + 2 * nb;
     l.a2 = l.count + 2;
-    l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [16R+8][xq] u16x4
-    l.work = l.s8 + 2 * (16 * R + 8) * xq;             // [nb*64*R] entries
+    l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [s8_rows][xq] u16x4
+    l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
     l.total = l.work + nb * 64 * R;
     return l;
+}
+
+__device__ __forceinline__ Layout layout_of(const SeaDev& d, int R)
+{
+    return make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq, d.s8_rows);
+}
+
+// The macroblock a wave owns inside its tile (waves are numbered row-major over the tile).
+struct WaveBlock {
+    int wr, wc;                   // position inside the tile
+    int brow, bcol;               // block coordinates in the frame
+    bool ok;                      // inside the frame's block grid (ragged last tile of a row / column)
+};
+__device__ __forceinline__ WaveBlock wave_block(const SeaDev& d, int trow, int bcol0, int wave)
+{
+    WaveBlock b;
+    b.wr = div_small(wave, d.magic_tc);
+    b.wc = wave - b.wr * d.tc;
+    b.brow = trow * d.tr + b.wr;
+    b.bcol = bcol0 + b.wc;
+    b.ok = b.bcol < d.nbc && b.brow < d.nbr;
+    return b;
 }
 
 // A: stage the common search window of the workgroup's blocks (coalesced dword loads; rows and
@@ -153,11 +170,12 @@ __device__ __forceinline__ void stage_window(const SeaDev& d, uint32_t* win, con
 // rows: per row two QSADs against a zero reference give the four horizontal 8-byte sums
 // r8(row, 4sq .. 4sq+3) (packed u16); the vertical 8-row sum slides with a ring of 8 rows in
 // registers: S8(y) = S8(y-1) + r8(y+7) - r8(y-1).  s8[y][sq] = packed S8(y, 4sq .. 4sq+3).
-template <int R>
-__device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
+// CH = s8_rows / 8 is a template parameter so that the ring indices and the warm-up are resolved
+// at compile time (a run-time row count cost 5 % of the whole search in guards).
+template <int CH>
+__device__ __forceinline__ void box_sums8_ch(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
 {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    constexpr int CH = 2 * R + 1;                      // 8 chunks cover 16R + 8 rows
     const int XQ = d.xq;
     for (int it = tid; it < 8 * XQ; it += blockDim.x) {
         const int ch = div_small(it, d.magic_xq), sq = it - ch * XQ;
@@ -180,6 +198,15 @@ __device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, 
             }
         }
     }
+}
+
+// s8_rows = 16R + 8 + 16 (tr - 1) is a multiple of 8 for every tile height: 8 chunks of 2R + 2 tr - 1 rows
+template <int R>
+__device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
+{
+    if (d.tr == 1) box_sums8_ch<2 * R + 1>(d, win, s8, tid);
+    else if (d.tr == 2) box_sums8_ch<2 * R + 3>(d, win, s8, tid);
+    else box_sums8_ch<2 * R + 7>(d, win, s8, tid);
 }
 
 // quadrant sums of the anchor held one dword per lane (lane = row * 4 + dword): the quad swap pairs
@@ -212,48 +239,75 @@ inline int pick_pitch(int need, int R)
     return best_p;
 }
 
-// Host: waves (= macroblocks) per workgroup and the LDS it needs.  More blocks share more of the
-// staged window and of the box-sum pass, but LDS per workgroup grows; pick the count that keeps
-// most waves resident per CU (160 KiB LDS, 32 waves), discounted by the idle waves of a ragged
-// last workgroup.  Returns false if nothing fits.
-inline bool plan(int R, int nbc, SeaDev* d, size_t* lds_bytes)
+// Host: tile shape (tr x tc macroblocks = waves per workgroup) and the LDS it needs.  A larger tile
+// shares more of the staged window and of the box-sum pass between its blocks (window bytes per
+// block: 1193 for 1 x 16, 864 for 2 x 8 at sw = 16), but LDS per workgroup grows.  The score is the
+// number of waves a CU keeps resident (160 KiB LDS, 32 waves), discounted by the idle waves of
+// ragged last tiles and by SIMD imbalance, with a bonus for the sharing.  GME_SEA_TILE = "TRxTC"
+// overrides it (A/B runs).  Returns false if nothing fits.
+inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
 {
-    auto bytes_for = [&](int nb_, int* pitch_out, int* xq_out) {
-        const int xq = (4 * R + 4 * (nb_ - 1) + 2) | 1;                 // S8 quads per row, odd pitch
-        const int need_dw = (nb_ - 1) * 4 + 3 * R + (R - 1) + 5;        // base + k + 4 pairs of two dwords
-        const int pitch = pick_pitch(need_dw > xq + 2 ? need_dw : xq + 2, R);
-        if (pitch_out) *pitch_out = pitch;
-        if (xq_out) *xq_out = xq;
-        return (size_t)make_layout(R, nb_, 16 * R + 15, pitch, xq).total * 4;
+    struct Shape { int tr, tc, pitch, xq; size_t bytes; };
+    auto shape = [&](int tr, int tc) {
+        Shape s;
+        s.tr = tr; s.tc = tc;
+        s.xq = (4 * R + 4 * (tc - 1) + 2) | 1;                          // S8 quads per row, odd pitch
+        const int need_dw = (tc - 1) * 4 + 3 * R + (R - 1) + 5;         // base + k + 4 pairs of two dwords
+        s.pitch = pick_pitch(need_dw > s.xq + 2 ? need_dw : s.xq + 2, R);
+        s.bytes = (size_t)make_layout(R, tr * tc, 16 * R + 15 + 16 * (tr - 1), s.pitch, s.xq, 16 * R + 8 + 16 * (tr - 1)).total * 4;
+        return s;
     };
-    int nb = 0;
+    Shape best = shape(1, 1);
     double best_score = -1.0;
-    for (int cand = 1; cand <= 16 && cand <= nbc; ++cand) {
-        const size_t bytes = bytes_for(cand, nullptr, nullptr);
-        if (bytes > 160 * 1024) break;
-        const int wgs = (int)((160 * 1024) / (bytes + 1024));           // allocation granularity slack
-        const int waves = wgs * cand > 32 ? 32 : wgs * cand;
-        const int per_row = (nbc + cand - 1) / cand;
-        // A workgroup's waves are dealt round robin to the CU's 4 SIMDs, so a wave count that is not a
-        // multiple of 4 leaves one SIMD with an extra wave for the whole search (measured: NB 16 vs 15
-        // +13 % at 720x480 sw 16; NB 8 vs 9 +17 % at 1080p sw 32) -> weigh by that imbalance.
-        const double simd_eff = (double)cand / (4 * ((cand + 3) / 4));
-        const double score = waves * ((double)nbc / (per_row * cand)) * simd_eff + cand * 1e-3;
-        if (score > best_score) { best_score = score; nb = cand; }
-    }
-    if (const char* e = getenv("GME_SEA_NB")) nb = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
-    if (nb > nbc) nb = nbc;
-    if (nb < 1) return false;
-    d->nb = nb;
-    d->wg_per_row = (nbc + nb - 1) / nb;
-    d->win_rows = 16 * R + 15;
-    *lds_bytes = bytes_for(nb, &d->pitch_dw, &d->xq);
-    d->rstep = 64 * nb / d->pitch_dw;
+    int force_tr = 0, force_tc = 0;
+    if (const char* e = getenv("GME_SEA_TILE")) sscanf(e, "%dx%d", &force_tr, &force_tc);
+    if (const char* e = getenv("GME_SEA_NB")) { force_tr = 1; force_tc = atoi(e); }
+    // resident waves per CU: 32 slots at <= 64 VGPRs (R <= 3); the R >= 4 kernels take up to 96 VGPRs -> 20
+    const int wave_cap = R <= 3 ? 32 : 20;
+    for (int pass = 0; pass < 2 && best_score < 0; ++pass)      // pass 0: SIMD-balanced wave counts only
+        for (int tr = 1; tr <= 4; tr *= 2)
+            for (int tc = 1; tc * tr <= 16; ++tc) {
+                if (force_tr > 0 && (tr != force_tr || tc != force_tc)) continue;
+                if (force_tr == 0 && (tc > nbc || (tr > 1 && tr > nbr) || (pass == 0 && (tr * tc) % 4 != 0))) continue;
+                const Shape s = shape(tr, tc);
+                if (s.bytes > 160 * 1024 || s.pitch >= 256 || s.xq >= 256) continue;
+                const int nb = tr * tc;
+                int wgs = (int)((160 * 1024) / (s.bytes + 1024));       // allocation granularity slack
+                if (wgs * nb > wave_cap) wgs = wave_cap / nb;
+                if (wgs < 1) wgs = 1;
+                const int waves = wgs * nb;
+                const double cover = ((double)nbc / (((nbc + tc - 1) / tc) * tc)) * ((double)nbr / (((nbr + tr - 1) / tr) * tr));
+                // A workgroup's waves are dealt round robin to the CU's 4 SIMDs, so a wave count that is not a
+                // multiple of 4 leaves one SIMD with an extra wave for the whole search (measured: 16 vs 15
+                // waves +13 % at 720x480 sw 16; 8 vs 9 +17 %, 8 vs 12 (VGPR-limited to one workgroup) +30 %
+                // at 1080p sw 32): such shapes are only used when nothing else fits.
+                const double simd_eff = (double)nb / (4 * ((nb + 3) / 4));
+                // staged window bytes per block, relative to a block's own (16 + 2 sw + 15)^2 window
+                const double area = (double)(16 * tr + 2 * sw + 15) * (16 * tc + 2 * sw + 15) / nb;
+                const double own = (double)(2 * sw + 31) * (2 * sw + 31);
+                const double share = 1.0 + SEA_SHARE_WEIGHT * (1.0 - area / own);
+                // a lone workgroup per CU has nobody to cover its barriers (measured 2-5 % at 1080p sw 32)
+                const double alone = wgs == 1 ? 0.93 : 1.0;
+                const double score = waves * cover * simd_eff * share * alone + nb * 1e-3;
+                if (score > best_score) { best_score = score; best = s; }
+            }
+    if (best_score < 0) return false;
+    d->tr = best.tr; d->tc = best.tc; d->nb = best.tr * best.tc;
+    d->magic_tc = div_magic(d->tc);
+    d->wg_per_row = (nbc + d->tc - 1) / d->tc;
+    d->tile_rows = (nbr + d->tr - 1) / d->tr;
+    d->wg_per_pair = d->wg_per_row * d->tile_rows;
+    d->win_rows = 16 * R + 15 + 16 * (d->tr - 1);
+    d->s8_rows = 16 * R + 8 + 16 * (d->tr - 1);
+    d->pitch_dw = best.pitch; d->xq = best.xq;
+    *lds_bytes = best.bytes;
+    d->rstep = 64 * d->nb / d->pitch_dw;
     d->magic_pitch = div_magic(d->pitch_dw);
     d->magic_xq = div_magic(d->xq);
-    return *lds_bytes <= 160 * 1024 && d->pitch_dw < 256 && d->xq < 256;
+    d->magic_wpp = div_magic40(d->wg_per_pair);
+    d->magic_wpr = div_magic40(d->wg_per_row);
+    return d->rstep >= 1;
 }
-
 
 // Persistent form of a search kernel: G workgroups (as many as fit on the chip at once) walk the
 // tiles of "their" XCD's pairs.  The window and anchor of the next tile are fetched into registers
@@ -279,7 +333,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
     if (tile >= ntiles) return;
 
     uint32_t wv[NV], an_next = 0;
-    int pair = 0, brow = 0, bcol0 = 0;
+    int pair = 0, trow = 0, bcol0 = 0;
     auto fetch = [&](int t) {
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -287,11 +341,11 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         const int row0 = div_small(tid, d.magic_pitch), dw = tid - row0 * d.pitch_dw;
         const int lp = (int)(((unsigned long long)(unsigned)t * d.magic_wpp) >> 40);
         const int wg = t - lp * d.wg_per_pair;
-        brow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
-        bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+        trow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
+        bcol0 = (wg - trow * d.wg_per_row) * d.tc;
         pair = lp * 8 + xcd;
         const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-        const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = brow * 16 - d.sw + row0;
+        const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = trow * d.tr * 16 - d.sw + row0;
         const bool colok = row0 < d.rstep && gx0 >= 0 && gx0 < d.pitch;
         const uint8_t* src = cur + (long long)gy0 * d.pitch + gx0;
         const long long sstep = (long long)d.rstep * d.pitch;
@@ -302,8 +356,9 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
             if (colok && row0 + u * d.rstep < d.win_rows && gy >= 0 && gy < d.H) wv[u] = *(const uint32_t*)(src + u * sstep);
         }
         an_next = 0;
-        if (bcol0 + wave < d.nbc) {
-            const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+        const WaveBlock wb = wave_block(d, trow, bcol0, wave);
+        if (wb.ok) {
+            const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(wb.brow * 16) * d.pitch + wb.bcol * 16;
             an_next = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
         }
     };
@@ -325,9 +380,9 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
                     if (row0 + u * d.rstep < d.win_rows) dst[u * dstep] = wv[u];
             }
         }
-        const int pair_c = pair, brow_c = brow, bcol0_c = bcol0;
+        const int pair_c = pair, trow_c = trow, bcol0_c = bcol0;
         const uint32_t mine = an_next;
-        const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, bcol0_c + wave < d.nbc, mine);
+        const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, wave_block(d, trow_c, bcol0_c, wave).ok, mine);
         if (tid == 0) {
             lds[L.count] = 0;
             if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
@@ -339,7 +394,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
             fetch(tile);
             if (ctr && tid == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
         }
-        Kern::phases(d, lds, L, pair_c, brow_c, bcol0_c, mine, pre, tid);
+        Kern::phases(d, lds, L, pair_c, trow_c, bcol0_c, mine, pre, tid);
         if (!more) break;
         __syncthreads();                                   // everyone is done with this tile's LDS
     }

@@ -64,7 +64,7 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
 
 // Phases A' .. F of one tile (entry conditions as tile_phases() of bbme_sea.hip, plus a2s[] filled).
 template <int R, bool E4>
-__device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+__device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                 uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid)
 {
     const int T = blockDim.x;
@@ -76,12 +76,12 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
     uint32_t* a2s = lds + L.a2;                                         // [NB] sum of squares of each anchor
     uint64_t* s8 = (uint64_t*)(lds + L.s8);
     uint32_t* work = lds + L.work;
-    const int r0 = brow * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int bcol = bcol0 + wave;
-    const bool wave_ok = bcol < d.nbc;
-    const int c0 = bcol * 16;
+    const WaveBlock wb = wave_block(d, trow, bcol0, wave);
+    const int brow = wb.brow, bcol = wb.bcol;
+    const bool wave_ok = wb.ok;
+    const int r0 = brow * 16, c0 = bcol * 16;
     const int prow = lane >> 2, q = lane & 3;
 
     // ---- A'
@@ -94,7 +94,7 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
     if (wave_ok) {
         const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
         uint32_t pkey[R];
-        const uint64_t* sp0 = s8 + (prow * R) * XQ + wave * 4 + q * R;
+        const uint64_t* sp0 = s8 + (16 * wb.wr + prow * R) * XQ + wb.wc * 4 + q * R;
         if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
             lower_bounds_mse<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
         else
@@ -119,8 +119,8 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
             for (int which = 0; which < 2; ++which) {
                 const int idx = which ? idx1 : idx0;
                 const int ci = idx / NC, ri = idx - ci * NC;
-                const int byte = wave * 16 + ci + 4 * aj;
-                const uint32_t* p = win + (ri + arow) * d.pitch_dw + (byte >> 2);
+                const int byte = wb.wc * 16 + ci + 4 * aj;
+                const uint32_t* p = win + (16 * wb.wr + ri + arow) * d.pitch_dw + (byte >> 2);
                 const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
                 const uint32_t part = mine2 + __builtin_amdgcn_udot4(v, v, 0u, false) - 2u * __builtin_amdgcn_udot4(v, mine, 0u, false);
                 const uint32_t ssd = wave_sum_u32(part);
@@ -155,6 +155,7 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
             active = (ent & 0xFFFFu) <= (uint32_t)(best[ent >> 25] >> 21);
         }
         const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+        const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;         // the patch's block inside the tile
         const int prow2 = l2 >> 2, q2 = l2 & 3;
         uint32_t acc[R][4];
 #pragma unroll
@@ -162,7 +163,7 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = 0;
         if (active) {
-            const uint32_t* lrow = win + (prow2 * R + AR * sub) * d.pitch_dw + w2 * 4 + q2 * R + k2;
+            const uint32_t* lrow = win + (16 * wr2 + prow2 * R + AR * sub) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
             const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + AR * 4 * sub;
 #pragma unroll
             for (int t = 0; t < R + AR - 1; ++t) {
@@ -205,18 +206,20 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
                 }
         }
         if (active && sub == 0) {
-            const int c02 = (bcol0 + w2) * 16;
+            const int c02 = (bcol0 + wc2) * 16, r02 = (trow * d.tr + wr2) * 16;
             const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+            const int lo_r2 = max(0, d.sw - r02), hi_r2 = min(NC - 1, d.H - 16 - r02 + d.sw);
+            const bool rows_inside2 = NC == 16 * R && lo_r2 == 0 && hi_r2 == NC - 1;
             const uint32_t a2 = a2s[w2];
             unsigned long long key = ~0ull;
             const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
-            const uint32_t* trow = tab + (long long)(r0 - d.sw + ri0) * d.pitch + (c02 - d.sw + ci0);
-            if (rows_inside && lo_c == 0 && hi_c == NC - 1) {
+            const uint32_t* tabrow = tab + (long long)(r02 - d.sw + ri0) * d.pitch + (c02 - d.sw + ci0);
+            if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
                 uint32_t b2[R][4];                             // all table reads in flight before the first use
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) b2[i][e4] = trow[(long long)i * d.pitch + e4];
+                    for (int e4 = 0; e4 < 4; ++e4) b2[i][e4] = tabrow[(long long)i * d.pitch + e4];
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4)
 #pragma unroll
@@ -232,8 +235,8 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         const int ri = ri0 + i;
-                        if (ri < lo_r || ri > hi_r) continue;
-                        const uint32_t cost = a2 + trow[(long long)i * d.pitch + e4] - 2u * acc[i][e4];
+                        if (ri < lo_r2 || ri > hi_r2) continue;
+                        const uint32_t cost = a2 + tabrow[(long long)i * d.pitch + e4] - 2u * acc[i][e4];
                         key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)(ci * NC + ri));
                     }
                 }
@@ -268,10 +271,10 @@ struct MseTile {
         }
         return p;
     }
-    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int brow, int bcol0,
+    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                   uint32_t mine, const Pre& p, int tid)
     {
-        tile_phases_mse<R, E4>(d, lds, L, pair, brow, bcol0, mine, p.a01, p.a23, p.mine2, tid);
+        tile_phases_mse<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, p.mine2, tid);
     }
 };
 
@@ -279,30 +282,30 @@ template <int R, bool E4>
 __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
-    const Layout L = make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq);
-    int pair, brow, bcol0;
-    if (!locate(d, &pair, &brow, &bcol0)) return;
+    const Layout L = layout_of(d, R);
+    int pair, trow, bcol0;
+    if (!locate(d, &pair, &trow, &bcol0)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // ---- A
-    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    stage_window(d, lds + L.win, d.cur + (long long)pair * d.plane_stride, bcol0, trow * d.tr * 16);
     uint32_t mine = 0;
-    const bool wave_ok = bcol0 + wave < d.nbc;
-    if (wave_ok) {
-        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(brow * 16) * d.pitch + (bcol0 + wave) * 16;
+    const WaveBlock wb = wave_block(d, trow, bcol0, wave);
+    if (wb.ok) {
+        const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(wb.brow * 16) * d.pitch + wb.bcol * 16;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
     }
-    const typename MseTile<R, E4>::Pre pre = MseTile<R, E4>::prep(d, lds, L, wave, lane, wave_ok, mine);
+    const typename MseTile<R, E4>::Pre pre = MseTile<R, E4>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (threadIdx.x == 0) lds[L.count] = 0;
     __syncthreads();
-    MseTile<R, E4>::phases(d, lds, L, pair, brow, bcol0, mine, pre, (int)threadIdx.x);
+    MseTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
 }
 
 template <int R, int NV>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
-    persistent_tiles<NV, MseTile<R, false>>(d, lds, make_layout(R, d.nb, d.win_rows, d.pitch_dw, d.xq));
+    persistent_tiles<NV, MseTile<R, false>>(d, lds, layout_of(d, R));
 }
 
 }  // namespace
@@ -327,10 +330,7 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.stamps = nullptr;
 #endif
     size_t lds = 0;
-    if (!plan(R, nbc, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
-    d.wg_per_pair = d.wg_per_row * nbr;
-    d.magic_wpp = div_magic40(d.wg_per_pair);
-    d.magic_wpr = div_magic40(d.wg_per_row);
+    if (!plan(R, nbr, nbc, job.sw, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
     const dim3 block(64 * d.nb);
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
