@@ -317,23 +317,23 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
     }
 }
 
-// 16x16 box sums of squares, two separable passes over one plane stack.
-// Pass 1: thread -> four horizontal 16-byte sums of squares at x .. x+3 (x % 4 == 0): five aligned
-// dwords, three v_alignbyte copies of each, sixteen v_dot4(b, b).  Pass 2: thread -> the same four
-// columns, sliding down a chunk of rows: S(y+1) = S(y) + r(y+16) - r(y).
+// 16x16 box sums of squares of one plane stack in ONE pass (5.5 bytes of HBM traffic per pixel
+// instead of the ~15 of a rows pass + a columns pass through a uint32 scratch plane).
+// Thread -> four adjacent columns x .. x+3 (x % 4 == 0) of a chunk of SQ_CHUNK output rows:
+//   h(row) = the four horizontal 16-byte sums of squares of `row`: five aligned dwords, three
+//            v_alignbyte copies of each, sixteen v_dot4(b, b);
+//   S(y)   = S(y-1) + h(y+15) - h(y-1), the last 16 h vectors held in a register ring (the row
+//            loop is unrolled in groups of 16 so that the ring indices are compile-time).
+// Each chunk re-walks 15 warm-up rows (1 byte per pixel, cheap next to the 4-byte outputs).
 typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+constexpr int SQ_CHUNK = 32;
 
-__global__ void __launch_bounds__(256) k_sqbox16_rows(const uint8_t* src, long long src_stride, int H, int W, int pitch,
-                                                      uint32_t* dst, long long dst_stride)
+__device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch)
 {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x > W - 16 || y >= H) return;
-    const uint32_t* p = (const uint32_t*)(src + (long long)blockIdx.z * src_stride + (long long)y * pitch + x);
+    const uint32_t* p = (const uint32_t*)row;
     uint32_t w[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[j] = (x + 4 * j < pitch) ? p[j] : 0u;     // last dword may lie past the pitch
-    u32x4_v out;
     uint32_t r[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -344,29 +344,38 @@ __global__ void __launch_bounds__(256) k_sqbox16_rows(const uint8_t* src, long l
             r[e] = __builtin_amdgcn_udot4(v, v, r[e], false);
         }
     }
+    u32x4_v out;
     out.x = r[0]; out.y = r[1]; out.z = r[2]; out.w = r[3];          // columns beyond W-16 are never read
-    *(u32x4_v*)(dst + (long long)blockIdx.z * dst_stride + (long long)y * pitch + x) = out;
+    return out;
 }
 
-constexpr int SQ_CHUNK = 32;
-
-__global__ void __launch_bounds__(256) k_sqbox16_cols(const uint32_t* rows, uint32_t* dst, long long stride, int H, int W,
-                                                      int pitch)
+__global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long src_stride, int H, int W, int pitch,
+                                                 uint32_t* dst, long long dst_stride)
 {
     const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SQ_CHUNK;
     if (x > W - 16 || y0 > H - 16) return;
-    const uint32_t* p = rows + (long long)blockIdx.z * stride + (long long)y0 * pitch + x;
-    uint32_t* o = dst + (long long)blockIdx.z * stride + (long long)y0 * pitch + x;
-    u32x4_v s = { 0, 0, 0, 0 };
+    const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y0 * pitch + x;
+    uint32_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y0 * pitch + x;
+    u32x4_v ring[16], s = { 0, 0, 0, 0 };
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += *(const u32x4_v*)(p + (long long)k * pitch);
-    *(u32x4_v*)o = s;
-    const int last = min(SQ_CHUNK - 1, H - 16 - y0);
-    for (int k = 1; k <= last; ++k) {
-        s += *(const u32x4_v*)(p + (long long)(k + 15) * pitch);
-        s -= *(const u32x4_v*)(p + (long long)(k - 1) * pitch);
-        *(u32x4_v*)(o + (long long)k * pitch) = s;
+    for (int r = 0; r < 15; ++r) {                       // rows y0 .. y0+14 <= H-2
+        ring[r] = sq_hsum4(p + (long long)r * pitch, x, pitch);
+        s += ring[r];
+    }
+    const int last = min(SQ_CHUNK - 1, H - 16 - y0);     // last output row of this chunk
+    for (int kb = 0; kb <= last; kb += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + u;
+            if (k <= last) {
+                const u32x4_v h = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);   // row y0+k+15 <= H-1
+                s += h;
+                *(u32x4_v*)(o + (long long)k * pitch) = s;
+                s -= ring[u];                            // h(y0 + k): row r lives in ring[r & 15]
+                ring[(u + 15) & 15] = h;
+            }
+        }
     }
 }
 
@@ -449,21 +458,18 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     return GME_OK;
 }
 
-// 16x16 box sums of squares for `count` planes: `tmp` and `out` are uint32 stacks with the
-// frame's pitch (elements) and `stride` elements between planes.
+// 16x16 box sums of squares for `count` planes: `out` is a uint32 stack with the frame's pitch
+// (elements) and `stride` elements between planes.
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
-                   uint32_t* tmp, uint32_t* out, long long stride)
+                   uint32_t* out, long long stride)
 {
     if (count == 0 || H < 16 || W < 16) return GME_OK;
     for (int first = 0; first < count; first += 32768) {
         const int n = count - first < 32768 ? count - first : 32768;
         const int xq = (W - 16) / 4 + 1;                            // column quads that hold a valid position
-        const dim3 g1((xq + 63) / 64, (H + 3) / 4, n);
-        const dim3 g2((xq + 63) / 64, ((H - 15 + SQ_CHUNK - 1) / SQ_CHUNK + 3) / 4, n);
-        hipLaunchKernelGGL(k_sqbox16_rows, g1, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W,
-                           pitch, tmp + first * stride, stride);
-        hipLaunchKernelGGL(k_sqbox16_cols, g2, dim3(256), 0, ctx->stream, tmp + first * stride, out + first * stride,
-                           stride, H, W, pitch);
+        const dim3 g((xq + 63) / 64, ((H - 15 + SQ_CHUNK - 1) / SQ_CHUNK + 3) / 4, n);
+        hipLaunchKernelGGL(k_sqbox16, g, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W, pitch,
+                           out + first * stride, stride);
     }
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
@@ -478,8 +484,8 @@ int bbme_aux_kind(int bs, int sw, int procedure, int pnorm)
 }
 
 int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
-                     int pitch, uint32_t* tmp, uint32_t* out, long long stride)
+                     int pitch, uint32_t* out, long long stride)
 {
-    if (kind == 1) return launch_sqbox16(ctx, src, src_stride, count, H, W, pitch, tmp, out, stride);
+    if (kind == 1) return launch_sqbox16(ctx, src, src_stride, count, H, W, pitch, out, stride);
     return GME_OK;
 }

@@ -203,7 +203,7 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     const size_t o_mf = c.take((size_t)h * w * 2 * sizeof(int32_t));
     const int aux = bbme_aux_kind(block_size, search_window, procedure, pnorm);
     const bool want_sq = aux != 0;
-    const size_t o_sq = c.take(want_sq ? plane * 4 : 0), o_sqtmp = c.take(want_sq ? plane * 4 : 0);
+    const size_t o_sq = c.take(want_sq ? plane * 4 : 0);
     void* base = nullptr;
     rc = ctx_scratch(ctx, c.off, &base);
     if (rc) return rc;
@@ -217,7 +217,7 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     job.bs = block_size; job.sw = search_window; job.procedure = procedure; job.pnorm = pnorm;
     job.mf = (int32_t*)(b + o_mf); job.sqbox_cur = nullptr; job.sqbox_stride = 0;
     if (want_sq) {
-        rc = launch_aux_table(ctx, aux, b + o_cur, 0, 1, H, W, pitch, (uint32_t*)(b + o_sqtmp), (uint32_t*)(b + o_sq), 0);
+        rc = launch_aux_table(ctx, aux, b + o_cur, 0, 1, H, W, pitch, (uint32_t*)(b + o_sq), 0);
         if (rc) return rc;
         job.sqbox_cur = (const uint32_t*)(b + o_sq);
     }
@@ -356,7 +356,6 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     plane_free(&s->comp);
     if (s->mv) hipFree(s->mv);
     for (int l = 0; l < 3; ++l) if (s->sqbox[l]) hipFree(s->sqbox[l]);
-    if (s->sqtmp) hipFree(s->sqtmp);
     if (s->params0) hipFree(s->params0);
     if (s->params_in) hipFree(s->params_in);
     if (s->sse) hipFree(s->sse);
@@ -464,10 +463,8 @@ static int seq_sqbox(gme_seq* s, int level, int kind)
     const size_t bytes = (size_t)p.stride * p.count * sizeof(uint32_t);
     int rc = ensure(&s->sqbox[level], &s->sqbox_bytes[level], bytes);
     if (rc) return rc;
-    rc = ensure(&s->sqtmp, &s->sqtmp_bytes, bytes);
-    if (rc) return rc;
     if (!s->sqbox_valid[level] || s->sqbox_kind[level] != kind) {
-        rc = launch_aux_table(s->ctx, kind, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqtmp, s->sqbox[level], p.stride);
+        rc = launch_aux_table(s->ctx, kind, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqbox[level], p.stride);
         if (rc) return rc;
         s->sqbox_valid[level] = true;
         s->sqbox_kind[level] = kind;

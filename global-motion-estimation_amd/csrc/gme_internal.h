@@ -81,8 +81,6 @@ struct gme_seq {
     size_t sqbox_bytes[3] = { 0, 0, 0 };
     bool sqbox_valid[3] = { false, false, false };
     int sqbox_kind[3] = { 0, 0, 0 };
-    uint32_t* sqtmp = nullptr;    // row-pass scratch, sized for the largest level in use
-    size_t sqtmp_bytes = 0;
     // GME state
     int gme_fd = 0, gme_bs = 0, gme_pairs = 0;
     int gme_procedure = 0, gme_sw = 0;
@@ -123,7 +121,7 @@ int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int c
 // 0 none, 1 = 16x16 box sums of squares (MSE, k_exh_dot16)
 int bbme_aux_kind(int bs, int sw, int procedure, int pnorm);
 int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
-                     int pitch, uint32_t* tmp, uint32_t* out, long long stride);
+                     int pitch, uint32_t* out, long long stride);
 bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm);
 
 int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
