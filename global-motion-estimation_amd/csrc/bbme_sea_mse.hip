@@ -170,24 +170,31 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
                 uint32_t w[5];
 #pragma unroll
                 for (int s = 0; s < 5; ++s) w[s] = lrow[t * d.pitch_dw + s];
-                uint32_t sh[4][4];                         // sh[j][e4] = bytes 4j+e4 .. 4j+e4+3 of the patch row
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sh[j][0] = w[j];
-#pragma unroll
-                    for (int e4 = 1; e4 < 4; ++e4) sh[j][e4] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)e4);
-                }
+                u32x4 ar[R];                               // anchor rows t - i that meet this window row
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int a = t - i;
-                    if (a < 0 || a > AR - 1) continue;
-                    const u32x4 ar = *(const u32x4*)(an + a * 4);
+                    if (a >= 0 && a <= AR - 1) ar[i] = *(const u32x4*)(an + a * 4);
+                }
+                // one window dword at a time: its four byte alignments (bytes 4j+e4 .. 4j+e4+3) live in four
+                // registers and feed the R x 4 accumulators, then the next dword reuses them
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t av = ar[j];
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t sh[4];
+                    sh[0] = w[j];
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = __builtin_amdgcn_udot4(sh[j][e4], av, acc[i][e4], false);
+                    for (int e4 = 1; e4 < 4; ++e4) sh[e4] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)e4);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int a = t - i;
+                        if (a < 0 || a > AR - 1) continue;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) acc[i][e4] = __builtin_amdgcn_udot4(sh[e4], ar[i][j], acc[i][e4], false);
                     }
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) asm volatile("" : "+v"(acc[i][e4]));
                 }
                 // keep the rows' dot products in program order (see k_exh_dot16)
 #pragma unroll
@@ -334,10 +341,10 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const dim3 block(64 * d.nb);
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
-    // The persistent form must hold the prefetched tile in registers next to phase E's 4R accumulators;
-    // at R = 3 (and R = 2 with many staging rows) that exceeds the 64 VGPRs of 8 waves/SIMD and the
-    // compiler would spill the prefetch itself -> those sizes keep the one-tile kernel.
-    const bool fits = R <= 1 || (R == 2 && nv <= 8) || R >= 4;
+    // The persistent form must hold the prefetched tile in registers next to phase E's 4R accumulators
+    // inside the 64 VGPRs of 8 waves/SIMD: only R = 3 with 16 staging rows per thread does not fit
+    // (the compiler would spill the prefetch itself) and keeps the one-tile kernel.
+    const bool fits = R != 3 || nv <= 12;
     if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
         if (pp.dynamic) {
