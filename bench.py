@@ -301,7 +301,8 @@ def main():
         if proc >= 0 and world == 1:
             # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
             # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
-            n_e2e = min(B, 256)
+            n_e2e = B                                              # same launch size as the timed steps: a profile of
+                                                                   # this command averages like-sized launches only
             host_frames = np.stack([seq.read_frame(i) for i in range(n_e2e + 1)])
             seq2 = native.Sequence(ctx, n_e2e + 1, H, W)          # its own small sequence: upload, search, read back
             seq2.upload(0, host_frames[:2])                        # first touch of the buffers outside the timing
