@@ -416,6 +416,28 @@ def test_sea_schedules_agree(mods, monkeypatch, mode):
         seq.close()
 
 
+@pytest.mark.parametrize("pnorm", [0, 1])
+def test_persistent_equals_one_tile_kernel_1080p(mods, monkeypatch, pnorm):
+    """BASELINE size (1920x1080, sw=32, R=5 windows): the persistent kernels (static and dynamic
+    schedule, prefetched tiles, 4-lane phase E for MAE) return exactly the fields of the
+    one-tile-per-workgroup kernels, which the golden/oracle tests pin at this size."""
+    native, _, _, _ = mods
+    ctx = native.default_context()
+    seq = native.Sequence(ctx, 4, 1080, 1920)
+    seq.synth(4321, 0)
+    fields = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("GME_SEA_PERSIST", mode)
+        seq.bbme(1, 16, 32, 0, pnorm)
+        fields[mode] = seq.read_mv()
+    seq.close()
+    assert fields["0"].shape == (3, 67, 120, 2)
+    assert np.array_equal(fields["1"], fields["0"]) and np.array_equal(fields["2"], fields["0"])
+    # the synthetic camera moves the background by (5, -3) per frame: most blocks must say so
+    mv = fields["0"].reshape(-1, 2)
+    assert np.mean((mv[:, 0] == 5) & (mv[:, 1] == -3)) > 0.7
+
+
 def test_full_size_1080p(golden, mods):
     """BASELINE configs 4/5 sizes: exhaustive MSE sw=32 and the GME stages at 1920x1080."""
     native, bbme, motion, _ = mods
