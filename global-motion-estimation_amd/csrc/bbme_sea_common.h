@@ -1,5 +1,6 @@
 // Shared pieces of the successive-elimination exhaustive kernels (bbme_sea.hip: MAE,
-// bbme_sea_mse.hip: MSE): launch descriptor, LDS layout, window staging, 8x8 box sums.
+// bbme_sea_mse.hip: MSE): launch descriptor, LDS layout, tile shapes, window staging, 8x8 box sums,
+// the persistent tile driver.
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,7 +73,7 @@ inline uint32_t div_magic(int dv) { return (1u << 20) / (uint32_t)dv + 1u; }
 inline unsigned long long div_magic40(int dv) { return (1ull << 40) / (unsigned long long)dv + 1ull; }
 __device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(__umul24((uint32_t)n, magic) >> 20); }
 
-// Workgroup -> (pair, block row, first block column).  Grid = (8 * wg_per_row, nbr, ceil(pairs / 8)):
+// Workgroup -> (pair, tile row, first block column).  Grid = (8 * wg_per_row, tile_rows, ceil(pairs / 8)):
 // workgroups go to the 8 XCDs round robin in x-fastest order, so the low 3 bits of blockIdx.x pick
 // the pair inside a group of 8 and all tiles of one pair land on one XCD (its L2 holds the pair).
 __device__ __forceinline__ bool locate(const SeaDev& d, int* pair, int* trow, int* bcol0)
