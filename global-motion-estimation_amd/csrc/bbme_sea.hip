@@ -388,7 +388,7 @@ template <int R, int NV>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
-    persistent_tiles<NV, MaeTile<R, (R >= 4)>>(d, lds, layout_of(d, R));
+    persistent_tiles<NV, MaeTile<R, (R >= 3)>>(d, lds, layout_of(d, R));
 }
 
 }  // namespace
@@ -451,9 +451,9 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     } else {
     dim3 grid;
     GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
-    // phase E with four lanes per patch pays for the large windows (measured: +11 % at sw 32, even at
-    // sw 16); GME_SEA_E4 = 0 / 1 overrides it for this one-tile kernel
-    const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : R >= 4;
+    // phase E with four lanes per patch (a quarter of the latency the other waves wait for): +11 % at
+    // sw 32, +3 % at sw 16 in the persistent kernel; GME_SEA_E4 = 0 / 1 overrides it for this one-tile kernel
+    const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : R >= 3;
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
     switch (R) {
