@@ -287,9 +287,10 @@ inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
                 const double area = (double)(16 * tr + 2 * sw + 15) * (16 * tc + 2 * sw + 15) / nb;
                 const double own = (double)(2 * sw + 31) * (2 * sw + 31);
                 const double share = 1.0 + SEA_SHARE_WEIGHT * (1.0 - area / own);
-                // a lone workgroup per CU has nobody to cover its barriers (measured 2-5 % at 1080p sw 32)
-                const double alone = wgs == 1 ? 0.93 : 1.0;
-                const double score = waves * cover * simd_eff * share * alone + nb * 1e-3;
+                // a lone workgroup per CU has nobody to cover its barriers (measured 2-5 % at 1080p sw 32); four
+                // 8-wave workgroups interleave better than two 16-wave ones (2 x 4 vs 2 x 8 tiles: +4.5 % at sw 16)
+                const double together = wgs == 1 ? 0.93 : 1.0 + 0.03 * ((wgs > 4 ? 4 : wgs) - 2);
+                const double score = waves * cover * simd_eff * share * together + nb * 1e-3;
                 if (score > best_score) { best_score = score; best = s; }
             }
     if (best_score < 0) return false;
