@@ -163,7 +163,9 @@ def main():
     gme = proc < 0
     # GME runs cut the resident pairs into `streams` ranges, each on its own HIP stream and host
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "3"))
+    # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
+    # not matter and concurrent persistent kernels only contend: 17.5 k pairs/s on one stream, 15 k on three)
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "3"))
     shard = None
     if proc == -3:
         import sequence

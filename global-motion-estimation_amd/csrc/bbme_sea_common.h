@@ -263,8 +263,8 @@ inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
     int force_tr = 0, force_tc = 0;
     if (const char* e = getenv("GME_SEA_TILE")) sscanf(e, "%dx%d", &force_tr, &force_tc);
     if (const char* e = getenv("GME_SEA_NB")) { force_tr = 1; force_tc = atoi(e); }
-    // resident waves per CU: 32 slots at <= 64 VGPRs (R <= 3); the R >= 4 kernels take up to 96 VGPRs -> 20
-    const int wave_cap = R <= 3 ? 32 : 20;
+    // resident waves per CU: 32 slots at <= 64 VGPRs (R <= 3); the R >= 4 kernels are held to 80 VGPRs -> 24
+    const int wave_cap = R <= 3 ? 32 : 24;
     for (int pass = 0; pass < 2 && best_score < 0; ++pass)      // pass 0: SIMD-balanced wave counts only
         for (int tr = 1; tr <= 4; tr *= 2)
             for (int tc = 1; tc * tr <= 16; ++tc) {
@@ -290,7 +290,10 @@ inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
                 // a lone workgroup per CU has nobody to cover its barriers (measured 2-5 % at 1080p sw 32); four
                 // 8-wave workgroups interleave better than two 16-wave ones (2 x 4 vs 2 x 8 tiles: +4.5 % at sw 16)
                 const double together = wgs == 1 ? 0.93 : 1.0 + 0.03 * ((wgs > 4 ? 4 : wgs) - 2);
-                const double score = waves * cover * simd_eff * share * together + nb * 1e-3;
+                // four-row tiles measured 3 % (720x480: 4 x 2 vs 2 x 4) to 15 % (1080p sw 32: 4 x 3 vs 2 x 6) slower
+                // than two-row tiles of the same size: their windows are tall, staging rows are short
+                const double tall = tr == 4 ? 0.95 : 1.0;
+                const double score = waves * cover * simd_eff * share * together * tall + nb * 1e-3;
                 if (score > best_score) { best_score = score; best = s; }
             }
     if (best_score < 0) return false;

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 }
 
 template <int R, int NV>
-__global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 5)) k_exh_sea16p_mse(SeaDev d)
+__global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 6)) k_exh_sea16p_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
     persistent_tiles<NV, MseTile<R, false>>(d, lds, layout_of(d, R));
