@@ -196,7 +196,6 @@ def main():
                 rows = sequence.gather_parameters(rows, shard.n_pairs_total, rank, dist.get_world_size(), gather_dev)
             last["rows"] = rows
     elif gme:
-        import motion
         last = {}
 
         def step():
