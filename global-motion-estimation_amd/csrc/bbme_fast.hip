@@ -464,8 +464,9 @@ int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int c
                    uint32_t* out, long long stride)
 {
     if (count == 0 || H < 16 || W < 16) return GME_OK;
-    for (int first = 0; first < count; first += 32768) {
-        const int n = count - first < 32768 ? count - first : 32768;
+    const int step = max_grid_planes();
+    for (int first = 0; first < count; first += step) {
+        const int n = count - first < step ? count - first : step;
         const int xq = (W - 16) / 4 + 1;                            // column quads that hold a valid position
         const dim3 g((xq + 63) / 64, ((H - 15 + SQ_CHUNK - 1) / SQ_CHUNK + 3) / 4, n);
         hipLaunchKernelGGL(k_sqbox16, g, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W, pitch,

@@ -334,7 +334,12 @@ int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
     // long sequences: keep every launch below ~16 M blocks so grid sizes stay far from 2^31
     const long long nblk = (long long)(job.H / job.bs) * (job.W / job.bs);
     if (nblk == 0 || job.pairs == 0) return GME_OK;
-    const long long per = (1ll << 24) / nblk < 1 ? 1 : (1ll << 24) / nblk;
+    long long cap = 1ll << 24;
+    if (const char* e = getenv("GME_BBME_CHUNK_BLOCKS")) {             // test hook: reach the chunked path with few pairs
+        const long long v = atoll(e);
+        if (v >= 1 && v <= (1ll << 24)) cap = v;
+    }
+    const long long per = cap / nblk < 1 ? 1 : cap / nblk;
     for (long long first = 0; first < job.pairs; first += per) {
         BbmeJob part = job;
         part.pairs = (int)(job.pairs - first < per ? job.pairs - first : per);

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "gme_internal.h"
@@ -47,12 +48,19 @@ extern "C" gme_ctx* gme_create(int device_id)
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         gme_set_error("gme_create: HIP initialisation failed on device %d: %s", device_id,
                       hipGetErrorString(hipGetLastError()));
+        if (ctx->status) hipFree(ctx->status);
+        if (ctx->ev0) hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
         delete ctx;
         return nullptr;
     }
     if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
         gme_set_error("gme_create: device %d is %s; this library carries gfx950 code only", device_id,
                       ctx->prop.gcnArchName);
+        hipFree(ctx->status);
+        hipEventDestroy(ctx->ev0);
+        hipEventDestroy(ctx->ev1);
         hipStreamDestroy(ctx->stream);
         delete ctx;
         return nullptr;
@@ -63,6 +71,7 @@ extern "C" gme_ctx* gme_create(int device_id)
 extern "C" void gme_destroy(gme_ctx* ctx)
 {
     if (!ctx) return;
+    { std::lock_guard<std::mutex> lock(ctx->mu); }        // let a call in flight on another thread finish
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
@@ -73,12 +82,15 @@ extern "C" void gme_destroy(gme_ctx* ctx)
     delete ctx;
 }
 
-static int ctx_enter(gme_ctx* ctx)
-{
-    GME_REQUIRE(ctx != nullptr, GME_ERR_ARG, "null context");
-    GME_HIP_TRY(hipSetDevice(ctx->device));
-    return GME_OK;
-}
+// Every entry point that touches a context holds its mutex for the whole call: the context owns ONE
+// stream and ONE growable scratch buffer, and ctypes releases the GIL, so two Python threads inside
+// the module-level bbme/motion/utils functions (one shared default context) would otherwise carve
+// the same scratch offsets or free the buffer under each other's kernels.  Calls on one context
+// serialise; use one context per thread (sequence.ShardedSequence does) for concurrency.
+#define GME_ENTER(c)                                                  \
+    GME_REQUIRE((c) != nullptr, GME_ERR_ARG, "null context");         \
+    std::lock_guard<std::mutex> gme_lock__((c)->mu);                  \
+    GME_HIP_TRY(hipSetDevice((c)->device))
 
 // wait for the stream and report a tripped in-kernel guard
 static int ctx_finish(gme_ctx* ctx)
@@ -96,8 +108,7 @@ static int ctx_finish(gme_ctx* ctx)
 
 extern "C" int gme_sync(gme_ctx* ctx)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
     return ctx_finish(ctx);
 }
 
@@ -114,16 +125,14 @@ extern "C" int gme_device_info(gme_ctx* ctx, char* name, int name_len, int* cu_c
 
 extern "C" int gme_timer_start(gme_ctx* ctx)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
     GME_HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     return GME_OK;
 }
 
 extern "C" int gme_timer_stop(gme_ctx* ctx, float* elapsed_ms)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
     GME_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     GME_HIP_TRY(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -187,8 +196,8 @@ struct Carver {
 extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int H, int W, int stride,
                            int block_size, int search_window, int procedure, int pnorm, int32_t* mf_out)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(prev && cur && mf_out, GME_ERR_ARG, "gme_bbme_u8: null pointer");
     GME_REQUIRE(H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_bbme_u8: bad shape H=%d W=%d stride=%d", H, W, stride);
     GME_REQUIRE(block_size >= 1, GME_ERR_ARG, "gme_bbme_u8: block_size %d", block_size);
@@ -229,8 +238,8 @@ extern "C" int gme_bbme_u8(gme_ctx* ctx, const uint8_t* prev, const uint8_t* cur
 
 extern "C" int gme_pyrdown_u8(gme_ctx* ctx, const uint8_t* src, int H, int W, int stride, uint8_t* dst)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(src && dst && H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_pyrdown_u8: bad arguments");
     Plane s, d;
     s.H = H; s.W = W; s.pitch = round_up(W, 64); s.stride = round_up(s.pitch * H, 256); s.count = 1;
@@ -250,8 +259,8 @@ extern "C" int gme_pyrdown_u8(gme_ctx* ctx, const uint8_t* src, int H, int W, in
 
 extern "C" int gme_affine_field(gme_ctx* ctx, const double params[6], int h, int w, int16_t* mf_out)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(params && mf_out && h >= 0 && w >= 0, GME_ERR_ARG, "gme_affine_field: bad arguments");
     if (h == 0 || w == 0) return GME_OK;
     Carver c;
@@ -270,8 +279,8 @@ extern "C" int gme_affine_field(gme_ctx* ctx, const double params[6], int h, int
 extern "C" int gme_compensate_u8(gme_ctx* ctx, const uint8_t* frame, int H, int W, int stride, const int32_t* mf,
                                  int h, int w, uint8_t* out)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(frame && mf && out && H > 0 && W > 0 && stride >= W, GME_ERR_ARG, "gme_compensate_u8: bad arguments");
     GME_REQUIRE(h > 0 && w > 0 && h <= H, GME_ERR_ARG,
                 "gme_compensate_u8: field of %d x %d blocks on a %d-row frame (motion.py:303 divides H by it)", h, w, H);
@@ -295,8 +304,8 @@ extern "C" int gme_compensate_u8(gme_ctx* ctx, const uint8_t* frame, int H, int 
 extern "C" int gme_sse_u8(gme_ctx* ctx, const uint8_t* a, const uint8_t* b_, int H, int W, int stride_a, int stride_b,
                           int64_t* sse_out)
 {
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(a && b_ && sse_out && H > 0 && W > 0 && stride_a >= W && stride_b >= W, GME_ERR_ARG,
                 "gme_sse_u8: bad arguments");
     const int pitch = round_up(W, 64);
@@ -323,7 +332,9 @@ extern "C" int gme_sse_u8(gme_ctx* ctx, const uint8_t* a, const uint8_t* b_, int
 // ---------------------------------------------------------------------------
 extern "C" gme_seq* gme_seq_create(gme_ctx* ctx, int n_frames, int H, int W)
 {
-    if (ctx_enter(ctx)) return nullptr;
+    if (!ctx) { gme_set_error("null context"); return nullptr; }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { gme_set_error("hipSetDevice(%d) failed", ctx->device); return nullptr; }
     if (n_frames < 1 || H < 1 || W < 1) { gme_set_error("gme_seq_create: bad shape"); return nullptr; }
     gme_seq* s = new (std::nothrow) gme_seq();
     if (!s) return nullptr;
@@ -347,6 +358,7 @@ static void free_fit(FitLevelBuf& f)
 extern "C" void gme_seq_destroy(gme_seq* s)
 {
     if (!s) return;
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     for (int l = 0; l < 3; ++l) { plane_free(&s->level[l]); free_fit(s->fit[l]); }
@@ -376,8 +388,7 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
                               int64_t frame_stride)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
     GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
                 "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
     const Plane& p = s->level[2];
@@ -400,8 +411,8 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
 extern "C" int gme_seq_synth(gme_seq* s, uint64_t seed, int t0)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
+    int rc = GME_OK;
     if (!s->synth_canvas) {
         if (hipMalloc((void**)&s->synth_canvas, (size_t)2048 * 4096) != hipSuccess) {
             gme_set_error("out of device memory (synthetic canvas)");
@@ -432,8 +443,7 @@ extern "C" int gme_seq_invalidate(gme_seq* s)
 extern "C" int gme_seq_read_frame(gme_seq* s, int level, int index, uint8_t* out)
 {
     GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_frame: null pointer");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
     GME_REQUIRE(level >= 0 && level <= 2 && index >= 0 && index < s->N, GME_ERR_ARG, "gme_seq_read_frame: bad index");
     GME_REQUIRE(level == 2 || s->pyramids_valid, GME_ERR_STATE, "pyramid levels exist only after gme_seq_gme_begin");
     const Plane& p = s->level[level];
@@ -475,8 +485,8 @@ static int seq_sqbox(gme_seq* s, int level, int kind)
 extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, int pnorm)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
+    int rc = GME_OK;
     GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
     GME_REQUIRE(bs >= 1, GME_ERR_ARG, "block_size %d", bs);
     rc = bbme_check_args(s->H, s->W, bs, sw, procedure, pnorm);
@@ -503,8 +513,7 @@ extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, i
 extern "C" int gme_seq_read_mv(gme_seq* s, int first_pair, int count, int32_t* mf_out)
 {
     GME_REQUIRE(s != nullptr && mf_out != nullptr, GME_ERR_ARG, "gme_seq_read_mv: null pointer");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
     GME_REQUIRE(s->mv != nullptr, GME_ERR_STATE, "gme_seq_read_mv before gme_seq_bbme");
     GME_REQUIRE(first_pair >= 0 && count >= 0 && first_pair + count <= s->mv_pairs, GME_ERR_ARG,
                 "gme_seq_read_mv: pairs [%d, %d) outside [0, %d)", first_pair, first_pair + count, s->mv_pairs);
@@ -574,8 +583,8 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     gme_ctx* ctx = s->ctx;
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
     GME_REQUIRE(bbme_bs >= 1, GME_ERR_ARG, "block_size %d", bbme_bs);
     const int pairs = s->N - fd;
@@ -674,8 +683,8 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
 {
     GME_REQUIRE(s != nullptr && params_in != nullptr && sums_out != nullptr, GME_ERR_ARG, "gme_seq_gme_fit: null pointer");
     gme_ctx* ctx = s->ctx;
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(level == 1 || level == 2 || level == -1, GME_ERR_ARG, "gme_seq_gme_fit: level %d (1, 2 or -1)", level);
     int pairs, level_H, level_W;
     const FitLevelBuf* f;
@@ -718,8 +727,8 @@ extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* 
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     gme_ctx* ctx = s->ctx;
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(level >= -1 && level <= 2 && pair >= 0 && pair < (level < 0 ? s->fit_mv_pairs : s->gme_pairs), GME_ERR_ARG,
                 "gme_seq_gme_read_stage: bad index");
     if (level >= 0) {
@@ -744,13 +753,13 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
 {
     GME_REQUIRE(s != nullptr && params != nullptr, GME_ERR_ARG, "gme_seq_compensate: null pointer");
     gme_ctx* ctx = s->ctx;
-    int rc = ctx_enter(ctx);
-    if (rc) return rc;
+    GME_ENTER(ctx);
+    int rc = GME_OK;
     GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
     const int pairs = s->N - fd;
-    GME_REQUIRE(pairs <= 65535, GME_ERR_ARG, "at most 65535 pairs per call");
+    GME_REQUIRE(bs >= 1, GME_ERR_ARG, "block_size %d", bs);
     const int h = s->H / bs, w = s->W / bs;
-    GME_REQUIRE(bs >= 1 && h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
+    GME_REQUIRE(h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
     if (!s->comp.ptr || s->comp.count != pairs) {
         plane_free(&s->comp);
         rc = plane_alloc(ctx, &s->comp, pairs, s->H, s->W);
@@ -779,8 +788,7 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
 extern "C" int gme_seq_read_compensated(gme_seq* s, int pair, uint8_t* out)
 {
     GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_compensated: null pointer");
-    int rc = ctx_enter(s->ctx);
-    if (rc) return rc;
+    GME_ENTER(s->ctx);
     GME_REQUIRE(s->comp.ptr && pair >= 0 && pair < s->comp.count, GME_ERR_STATE, "gme_seq_read_compensated: no such pair");
     GME_HIP_TRY(hipMemcpy2DAsync(out, s->W, s->comp.at(pair), s->comp.pitch, s->W, s->H, hipMemcpyDeviceToHost, s->ctx->stream));
     return ctx_finish(s->ctx);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct Plane {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct gme_ctx {
+    std::mutex mu;                // held by every C-ABI entry point for the whole call (gme_api.hip: GME_ENTER)
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -127,6 +129,7 @@ bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm);
 int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
 
 // ---- gme_kernels.hip --------------------------------------------------------
+int max_grid_planes();
 int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst);
 int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0);
 int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params,

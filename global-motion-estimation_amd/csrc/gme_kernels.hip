@@ -7,6 +7,8 @@
 // Floating point: every float64 operation below is written with the *_rn intrinsics,
 // so no FMA contraction can change a rounding; the sums reproduce the reference's
 // sequential `acc += (product) * w` order bit for bit.
+#include <stdlib.h>
+
 #include "gme_internal.h"
 
 namespace {
@@ -476,6 +478,14 @@ __global__ void __launch_bounds__(256) k_sse(const uint8_t* a, long long a_strid
 
 }  // namespace
 
+// Planes / pairs one launch may put in grid.y or grid.z (hardware limit 65535).  GME_MAX_GRID_PAIRS
+// lowers it so that tests reach the chunked paths with a handful of pairs.
+int max_grid_planes()
+{
+    if (const char* e = getenv("GME_MAX_GRID_PAIRS")) { const int v = atoi(e); if (v >= 1 && v <= 32768) return v; }
+    return 32768;
+}
+
 int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
 {
     GME_REQUIRE(dst.H == (src.H + 1) / 2 && dst.W == (src.W + 1) / 2 && dst.count == src.count, GME_ERR_ARG,
@@ -484,15 +494,19 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
     int x_end = (((src.W - 12) / 2 + 4) < dst.W ? ((src.W - 12) / 2 + 4) : dst.W) & ~3;
     if (x_end < 4) x_end = 4;
     const int interior_quads = (x_end - 4) / 4;
-    if (interior_quads > 0) {
-        const dim3 grid((interior_quads + 63) / 64, (dst.H + 3) / 4, src.count);
-        hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
-                           src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
-    }
     const int per_row = (dst.W < 4 ? dst.W : 4) + (dst.W - x_end > 0 ? dst.W - x_end : 0);
-    const dim3 egrid((dst.H * per_row + 255) / 256, 1, src.count);
-    hipLaunchKernelGGL(k_pyrdown_edge, egrid, dim3(256), 0, ctx->stream, src.ptr, (long long)src.stride, src.H, src.W,
-                       src.pitch, dst.ptr, (long long)dst.stride, dst.H, dst.W, dst.pitch);
+    const int step = max_grid_planes();
+    for (int first = 0; first < src.count; first += step) {            // grid.z holds at most 65535 planes
+        const int n = src.count - first < step ? src.count - first : step;
+        if (interior_quads > 0) {
+            const dim3 grid((interior_quads + 63) / 64, (dst.H + 3) / 4, n);
+            hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.at(first), (long long)src.stride, src.H, src.W,
+                               src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
+        }
+        const dim3 egrid((dst.H * per_row + 255) / 256, 1, n);
+        hipLaunchKernelGGL(k_pyrdown_edge, egrid, dim3(256), 0, ctx->stream, src.at(first), (long long)src.stride, src.H, src.W,
+                           src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
+    }
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }
@@ -508,7 +522,12 @@ int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blo
 int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out)
 {
     if (pairs == 0 || h * w == 0) return GME_OK;
-    hipLaunchKernelGGL(k_affine_field, dim3((h * w + 255) / 256, pairs), dim3(256), 0, ctx->stream, params, h, w, out);
+    const int step = max_grid_planes();
+    for (int first = 0; first < pairs; first += step) {
+        const int n = pairs - first < step ? pairs - first : step;
+        hipLaunchKernelGGL(k_affine_field, dim3((h * w + 255) / 256, n), dim3(256), 0, ctx->stream, params + (size_t)first * 6,
+                           h, w, out + (size_t)first * h * w * 2);
+    }
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }
@@ -533,6 +552,18 @@ int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride,
                       int out_pitch, const uint8_t* cur, int64_t cur_stride, unsigned long long* sse)
 {
     if (pairs == 0) return GME_OK;
+    const int step = max_grid_planes();
+    if (pairs > step) {                                                 // grid.z holds at most 65535 pairs
+        for (int first = 0; first < pairs; first += step) {
+            const int n = pairs - first < step ? pairs - first : step;
+            const int rc = launch_compensate(ctx, frames + (int64_t)first * frame_stride, frame_stride, n, H, W, pitch,
+                                             mf32 ? mf32 + (size_t)first * h * w * 2 : nullptr, params ? params + (size_t)first * 6 : nullptr,
+                                             h, w, out + (int64_t)first * out_stride, out_stride, out_pitch,
+                                             cur ? cur + (int64_t)first * cur_stride : nullptr, cur_stride, sse ? sse + first : nullptr);
+            if (rc) return rc;
+        }
+        return GME_OK;
+    }
     if (sse) GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
     const dim3 grid((W + 255) / 256, (H + COMP_ROWS - 1) / COMP_ROWS, pairs);
     if (h > 0 && (H / h) % 16 == 0 && W % 16 == 0 && pitch % 16 == 0 && out_pitch % 16 == 0 && frame_stride % 16 == 0 &&
@@ -554,9 +585,13 @@ int launch_sse(gme_ctx* ctx, const uint8_t* a, int64_t a_stride, int a_pitch, co
 {
     if (pairs == 0) return GME_OK;
     GME_HIP_TRY(hipMemsetAsync(sse, 0, sizeof(unsigned long long) * pairs, ctx->stream));
-    const dim3 grid((W + 63) / 64, (H + 3) / 4, pairs);
-    hipLaunchKernelGGL(k_sse, grid, dim3(256), 0, ctx->stream, a, (long long)a_stride, a_pitch, b, (long long)b_stride,
-                       b_pitch, H, W, sse);
+    const int step = max_grid_planes();
+    for (int first = 0; first < pairs; first += step) {
+        const int n = pairs - first < step ? pairs - first : step;
+        const dim3 grid((W + 63) / 64, (H + 3) / 4, n);
+        hipLaunchKernelGGL(k_sse, grid, dim3(256), 0, ctx->stream, a + (int64_t)first * a_stride, (long long)a_stride, a_pitch,
+                           b + (int64_t)first * b_stride, (long long)b_stride, b_pitch, H, W, sse + first);
+    }
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }

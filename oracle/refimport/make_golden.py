@@ -25,6 +25,13 @@ What the files hold:
                 compensated-frame hashes, PSNR per pair (results.py:41-112 flow)
   g8_next       SURVEY §8(f): hierarchical_wrapper, rescale_motion_field, psnr_records strings,
                 some_data output
+  g9_pan240seq  the reference's 51-frame real sequence (docs/assets/gifs/pan240, 320x240, mode P ->
+                convert('L')): results.py flow at (bs 16, fd 1) and at the slides' (bs 12, fd 5):
+                params, model field, compensated-frame hash, PSNR per pair, psnr_records strings,
+                some_data output; exhaustive MAE/MSE fields of frames 10 vs 13 (BASELINE configs[0])
+  g10_extra     BASELINE configs[3] at full size: 1920x1080 exhaustive-MSE (sw 32) fields at pyramid
+                levels 1 and 2 fed to the reference's own fit (motion.get_motion_field rebound,
+                SURVEY.md §0 D9), stage dump; motion.best_affine_parameters (motion.py:33-88) goldens
 """
 import hashlib
 import os
@@ -151,14 +158,17 @@ class _NumpyTap:
         return getattr(np, name)
 
 
-def gme_stage_dump(prev, cur, prefix, data, bbme_bs=16):
-    """Run the reference GME with taps on its internal calls; store every stage."""
+def gme_stage_dump(prev, cur, prefix, data, bbme_bs=16, gmf=None, final=True):
+    """Run the reference GME with taps on its internal calls; store every stage.
+    `gmf` replaces bbme.get_motion_field inside motion (the fit applied to another
+    search's field); the reference's own function otherwise."""
     log = []
     calls = []
     real_gmf, real_aff = motion.get_motion_field, motion.get_motion_field_affine
+    use_gmf = gmf or real_gmf
 
     def tap_gmf(*a, **k):
-        r = real_gmf(*a, **k)
+        r = use_gmf(*a, **k)
         calls.append(("gt", r.copy()))
         return r
 
@@ -200,6 +210,8 @@ def gme_stage_dump(prev, cur, prefix, data, bbme_bs=16):
         data[prefix + "l%d_Sx" % lvl] = ent[1][1]
         data[prefix + "l%d_Sy" % lvl] = ent[3][1]
     data[prefix + "params"] = params
+    if not final:
+        return params, None
     motion.BBME_BLOCK_SIZE = bbme_bs
     try:
         shape = (prev.shape[0] // bbme_bs, prev.shape[1] // bbme_bs)
@@ -484,8 +496,123 @@ def g8(pool):
     np.savez_compressed(os.path.join(OUT, "g8_next.npz"), **data)
 
 
+GIF = "/root/reference/docs/assets/gifs/pan240"
+
+
+def pan240_frames():
+    from PIL import Image
+    return [np.array(Image.open(os.path.join(GIF, "pan240-%d.png" % i)).convert("L"), dtype=np.uint8) for i in range(51)]
+
+
+def _g9_job(args):
+    bs, fd, i = args
+    frames = pan240_frames()
+    prev, cur = frames[i - fd], frames[i]
+    old = motion.BBME_BLOCK_SIZE
+    motion.BBME_BLOCK_SIZE = bs
+    try:                                     # results.py:47-59,109 with the authors' patched block size
+        params = motion.global_motion_estimation(prev, cur)
+        field = motion.get_motion_field_affine((int(prev.shape[0] / bs), int(prev.shape[1] / bs), 2), parameters=params)
+        comp = motion.compensate_frame(prev, field)
+    finally:
+        motion.BBME_BLOCK_SIZE = old
+    return bs, fd, i, params, field, sha(comp), str(utils.PSNR(cur, comp))
+
+
+def g9(pool):
+    """Real-content sequence: the 51 GIF frames of pan240 through the results.py flow."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    frames = pan240_frames()
+    data = {"frames": np.stack(frames)}
+    jobs = [(16, 1, i) for i in range(1, 51)] + [(12, 5, i) for i in range(5, 51)]
+    recs = {(16, 1): {}, (12, 5): {}}
+    for bs, fd, i, params, field, csha, ps in pool.map(_g9_job, jobs, chunksize=2):
+        k = "bs%d_fd%d_i%d_" % (bs, fd, i)
+        data[k + "params"] = params
+        data[k + "field"] = field
+        data[k + "comp_sha"] = csha
+        recs[(bs, fd)][str(i)] = ps
+    for (bs, fd), rec in recs.items():
+        rec = {str(i): rec[str(i)] for i in range(fd, 51)}
+        data["bs%d_fd%d_psnr_records_json" % (bs, fd)] = json.dumps(rec)
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(rec, f)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            utils.some_data(f.name)
+        os.unlink(f.name)
+        data["bs%d_fd%d_some_data_stdout" % (bs, fd)] = out.getvalue()
+    # BASELINE configs[0]: "frame 10 vs 13, bs=16 sw=16 exhaustive" on the decodable stand-in for the mp4
+    for pn in (0, 1):
+        data["exh_10_13_pn%d" % pn] = pool.apply(_mf_job, ((frames[10], frames[13], 16, 16, 0, pn),))
+    np.savez_compressed(os.path.join(OUT, "g9_pan240seq.npz"), **data)
+
+
+def _g10_strip(args):
+    """Reference exhaustive MSE sw=32 on a strip of pyramid level 1 (540x960) of the 1080p pair."""
+    r_lo, r_hi, top, bot = args
+    p, c = synth.frame(4321, 0, 1080, 1920), synth.frame(4321, 1, 1080, 1920)
+    p1, c1 = utils.get_pyramids(p)[1], utils.get_pyramids(c)[1]
+    mf = bbme.get_motion_field(p1[top:bot], c1[top:bot], block_size=16, search_window=32,
+                               searching_procedure=0, pnorm_distance=1)
+    return r_lo, r_hi, (r_lo * 16 - top) // 16, mf
+
+
+def _g10_bap(tag):
+    if tag == "small":
+        p, c = synth.frame(77, 3, 128, 192), synth.frame(77, 4, 128, 192)
+    elif tag == "pan240":
+        p, c = load_png("pan240-prev-frame.png"), load_png("pan240-curr-frame.png")
+    else:
+        p, c = synth.frame(1234, 0, 480, 720), synth.frame(1234, 1, 480, 720)
+    return tag, motion.best_affine_parameters(p, c)
+
+
+def g10(pool):
+    data = {}
+    # ---- BASELINE configs[3]: exhaustive MSE sw=32 at levels 1 and 2, then the reference's fit
+    p, c = synth.frame(4321, 0, 1080, 1920), synth.frame(4321, 1, 1080, 1920)
+    H1, bs, sw = 540, 16, 32
+    nbr = H1 // bs                     # 33
+    jobs, per = [], 5
+    for lo in range(0, nbr, per):
+        hi = min(nbr, lo + per)
+        top = max(0, lo * bs - sw)
+        bot = min(H1, (hi - 1) * bs + (sw + bs - 1) + bs)
+        top -= top % bs
+        jobs.append((lo, hi, top, bot))
+    bap = pool.map_async(_g10_bap, ["small", "pan240", "synth720"])
+    mf1 = np.zeros((nbr, 960 // bs, 2), np.int32)
+    for lo, hi, off, part in pool.map(_g10_strip, jobs):
+        mf1[lo:hi] = part[off:off + (hi - lo)]
+    mf2 = np.load(os.path.join(OUT, "g5_1080p.npz"))["exh_mse_sw32"]      # level 2 = the full frame (g5)
+    fields = {mf1.shape: mf1, mf2.shape: mf2}
+
+    def exhaustive_gmf(previous, current, block_size=4, search_window=2, searching_procedure=1, pnorm_distance=1):
+        if block_size == 2:            # the dense first estimate stays the reference's diamond search
+            return bbme.get_motion_field(previous, current, block_size=block_size, search_window=search_window,
+                                         searching_procedure=searching_procedure, pnorm_distance=pnorm_distance)
+        return fields[(previous.shape[0] // block_size, previous.shape[1] // block_size, 2)].copy()
+
+    data["gme1080exh_l1_exh_mse_sw32"] = mf1
+    gme_stage_dump(p, c, "gme1080exh_", data, gmf=exhaustive_gmf, final=False)
+    params = data["gme1080exh_params"]
+    field = motion.get_motion_field_affine((1080 // 16, 1920 // 16, 2), params)
+    comp = motion.compensate_frame(p, field)
+    data["gme1080exh_field"] = field
+    data["gme1080exh_comp_sha"] = sha(comp)
+    data["gme1080exh_psnr"] = np.float64(utils.PSNR(c, comp).real)
+    # ---- motion.best_affine_parameters (motion.py:33-88, no mask)
+    for tag, out in bap.get():
+        data["bap_%s" % tag] = out
+    np.savez_compressed(os.path.join(OUT, "g10_extra.npz"), **data)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     os.makedirs(OUT, exist_ok=True)
     with Pool(8) as pool:
         for name in which:

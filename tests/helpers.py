@@ -114,6 +114,37 @@ def np_oracle():
     return gme_oracle
 
 
+def oracle_gme(prev, cur, procedure=3, sw=2, bs=16, frac=0.3):
+    """motion.global_motion_estimation (motion.py:109-136) through the C oracle with a selectable BBME
+    at levels 1-2 (BASELINE configs[3] fits the affine model to an exhaustive-search
+    field; the reference itself hard-codes diamond = procedure 3) -> (params, [level-1, level-2 stage])."""
+    co, o = c_oracle(), np_oracle()
+    pp = [co.pyrdown(co.pyrdown(prev)), co.pyrdown(prev), prev]
+    cp = [co.pyrdown(co.pyrdown(cur)), co.pyrdown(cur), cur]
+    dense = co.bbme(pp[0], cp[0], 2, 2, 3, 1)
+    params = co.first_parameters(dense)
+    stages = []
+    for lvl in (1, 2):
+        params = o.project_parameters(params)
+        gt = co.bbme(pp[lvl], cp[lvl], bs, sw, procedure, 1)
+        st = co.fit_level(gt, params, frac, pp[lvl].shape)
+        st["gt"] = gt
+        st["params_in"] = np.array(params, copy=True)
+        st["dense"] = dense
+        stages.append(st)
+        params = o.solve_parameters(st["F"], st["Sx"], st["Sy"])
+    return params, stages
+
+
+def oracle_results_flow(prev, cur, bs=16, procedure=3, sw=2):
+    """results.py:50-59,109 for one pair through the C oracle -> (params, field int16, compensated, psnr.real)."""
+    co, o = c_oracle(), np_oracle()
+    params, _ = oracle_gme(prev, cur, procedure, sw, bs)
+    field = co.affine_field(params, int(prev.shape[0] / bs), int(prev.shape[1] / bs))
+    comp = co.compensate(prev, field.astype(np.int32))
+    return params, field, comp, o.psnr(cur, comp)
+
+
 def sha(a):
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

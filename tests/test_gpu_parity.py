@@ -11,7 +11,7 @@ import re
 import numpy as np
 import pytest
 
-from helpers import c_oracle, np_oracle, sha
+from helpers import c_oracle, np_oracle, oracle_gme, oracle_results_flow, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -461,21 +461,7 @@ def test_full_size_1080p(golden, mods):
 
 
 def _oracle_gme(prev, cur, procedure, sw, bs=16, frac=0.3):
-    """motion.global_motion_estimation through the C oracle with a selectable BBME at levels 1-2
-    (BASELINE config 4 fits the affine model to an exhaustive-search field)."""
-    co, o = c_oracle(), np_oracle()
-    pp = [co.pyrdown(co.pyrdown(prev)), co.pyrdown(prev), prev]
-    cp = [co.pyrdown(co.pyrdown(cur)), co.pyrdown(cur), cur]
-    params = co.first_parameters(co.bbme(pp[0], cp[0], 2, 2, 3, 1))
-    stages = []
-    for lvl in (1, 2):
-        params = o.project_parameters(params)
-        gt = co.bbme(pp[lvl], cp[lvl], bs, sw, procedure, 1)
-        st = co.fit_level(gt, params, frac, pp[lvl].shape)
-        st["gt"] = gt
-        stages.append(st)
-        params = o.solve_parameters(st["F"], st["Sx"], st["Sy"])
-    return params, stages
+    return oracle_gme(prev, cur, procedure, sw, bs, frac)
 
 
 @pytest.mark.parametrize("procedure,sw", [(0, 8), (0, 16), (1, 7), (2, 6)])

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from helpers import c_oracle, np_oracle, sha
+from helpers import c_oracle, np_oracle, oracle_gme, oracle_results_flow, sha
 
 G1_KEY = re.compile(r"mf_(\w+?_\d+x\d+)_bs(\d+)_sw(\d+)_sp(\d)_pn(\d)$")
 
@@ -330,3 +330,84 @@ def test_c_oracle_1080p(golden):
         assert np.array_equal(st["mask"], g["gme_l%d_mask" % lvl])
         for k in ("F", "Sx", "Sy"):
             assert st[k].tobytes() == np.ascontiguousarray(g["gme_l%d_%s" % (lvl, k)]).tobytes()
+
+
+def test_c_oracle_pan240_sequence(golden):
+    """The reference's own 51-frame real sequence (docs/assets/gifs/pan240) through its results.py flow
+    (results.py:41-112) at the code default (bs 16, fd 1) and at the slides' setting (bs 12, fd 5,
+    docs/presentation/main.tex:382): parameters, model field, compensated frame, PSNR per pair."""
+    import json
+    g = golden("g9_pan240seq")
+    frames = g["frames"]
+    assert frames.shape == (51, 240, 320) and frames.dtype == np.uint8
+    for bs, fd in ((16, 1), (12, 5)):
+        rec = json.loads(str(g["bs%d_fd%d_psnr_records_json" % (bs, fd)]))
+        assert list(rec) == [str(i) for i in range(fd, 51)]
+        for i in range(fd, 51):
+            k = "bs%d_fd%d_i%d_" % (bs, fd, i)
+            params, field, comp, psnr = oracle_results_flow(frames[i - fd], frames[i], bs)
+            np.testing.assert_allclose(params, g[k + "params"], rtol=1e-10, atol=1e-12, err_msg=k)
+            assert np.array_equal(field, g[k + "field"]), k
+            assert sha(comp) == str(g[k + "comp_sha"]), k
+            assert abs(psnr - complex(rec[str(i)]).real) < 1e-12, k
+    co = c_oracle()
+    for pn in (0, 1):       # BASELINE configs[0]: frame 10 vs 13, bs 16 sw 16 exhaustive
+        assert np.array_equal(co.bbme(frames[10], frames[13], 16, 16, 0, pn), g["exh_10_13_pn%d" % pn]), pn
+
+
+def test_rounding_margin_of_sequence_goldens(golden):
+    """Same margin check as test_rounding_margin_of_goldens for the 96 real-content pairs."""
+    g = golden("g9_pan240seq")
+    worst = 1.0
+    for bs, fd in ((16, 1), (12, 5)):
+        h, w = 240 // bs, 320 // bs
+        i, j = np.mgrid[0:h, 0:w]
+        for idx in range(fd, 51):
+            p = np.asarray(g["bs%d_fd%d_i%d_params" % (bs, fd, idx)], np.float64)
+            for a in (0, 3):
+                d = (p[a] + p[a + 2] * j) + p[a + 1] * i
+                worst = min(worst, np.abs(d - np.floor(d) - 0.5).min())
+    assert worst > 1e-9, worst
+
+
+def test_c_oracle_gme1080exh(golden):
+    """BASELINE configs[3] at full size: exhaustive MSE sw=32 fields at pyramid levels 1 and 2 of the
+    1920x1080 pair, then the reference's own fit applied to them."""
+    import synth
+    g = golden("g10_extra")
+    co = c_oracle()
+    p, c = synth.frame(4321, 0, 1080, 1920), synth.frame(4321, 1, 1080, 1920)
+    params, stages = oracle_gme(p, c, 0, 32)
+    assert np.array_equal(stages[0]["dense"], g["gme1080exh_dense"])
+    assert np.array_equal(stages[0]["gt"], g["gme1080exh_l1_exh_mse_sw32"])
+    for lvl in (1, 2):
+        pre = "gme1080exh_l%d_" % lvl
+        st = stages[lvl - 1]
+        assert np.array_equal(st["gt"], g[pre + "gt"]), lvl
+        np.testing.assert_allclose(st["params_in"], g[pre + "params_in"], rtol=1e-10, atol=1e-12)
+        st = co.fit_level(st["gt"], g[pre + "params_in"], 0.3, (1080 >> (2 - lvl), 1920 >> (2 - lvl)))
+        assert np.array_equal(st["model"], g[pre + "model"]) and st["thr"] == int(g[pre + "thr"])
+        assert np.array_equal(st["mask"], g[pre + "mask"])
+        for k in ("F", "Sx", "Sy"):
+            assert st[k].tobytes() == np.ascontiguousarray(g[pre + k]).tobytes(), (lvl, k)
+    np.testing.assert_allclose(params, g["gme1080exh_params"], rtol=1e-10, atol=1e-12)
+    field = co.affine_field(params, 67, 120)
+    assert np.array_equal(field, g["gme1080exh_field"])
+    comp = co.compensate(p, field.astype(np.int32))
+    assert sha(comp) == str(g["gme1080exh_comp_sha"])
+    assert abs(np_oracle().psnr(c, comp) - float(g["gme1080exh_psnr"])) < 1e-12
+
+
+def test_oracle_unmasked_fit(golden):
+    """motion.best_affine_parameters (motion.py:33-88): diamond MSE field, no mask, x = 4i, y = 4j."""
+    import synth
+    g = golden("g10_extra")
+    g3 = golden("g3_docframes")
+    co, o = c_oracle(), np_oracle()
+    cases = {"small": (synth.frame(77, 3, 128, 192), synth.frame(77, 4, 128, 192)),
+             "pan240": (g3["in_pan240_prev"], g3["in_pan240_cur"]),
+             "synth720": (synth.frame(1234, 0, 480, 720), synth.frame(1234, 1, 480, 720))}
+    for tag, (p, c) in cases.items():
+        gt = co.bbme(p, c, 16, 2, 3, 1)
+        F, Sx, Sy = o.normal_sums(gt, np.zeros(gt.shape[:2], bool), p.shape)
+        np.testing.assert_allclose(o.solve_parameters(F, Sx, Sy), g["bap_" + tag], rtol=1e-10, atol=1e-12, err_msg=tag)
