@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X hot path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W            # N=1 directly
+    python bench.py --gpus N --steps K --warmup W            # N=1 directly (no torch in the process)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over this rank's batch of synthetic frame pairs,
-frames already resident in HBM.  Default workload = BASELINE.json configs[1]:
-720x480 synthetic luma, bs=16, sw=16, exhaustive search, MAE.  Frame pairs shard across
-ranks with no data-path collective ("weak" scaling: every rank holds its own batch);
-torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+One "step" = one pass of the hot path over this rank's batch of frame pairs, frames already resident
+in HBM.  Default workload = BASELINE.json configs[1]: 720x480 synthetic luma, bs=16, sw=16, exhaustive
+search, MAE.  Frame pairs shard across ranks with no data-path collective ("weak" scaling: every rank
+holds its own batch); the only exchange of the path is the all-gather of per-pair parameter rows of
+config seq1080 (BASELINE configs[4]), which goes through the library's own RCCL entry point
+(gme_comm_*, include/gme_hip.h) like the barriers and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      HBM view of the dominant kernel: algorithmic bytes / HIP-event kernel time
-  cpu_baseline  the NumPy oracle (reference loop structure) timed on one host core over a
-                bounded sample of the same workload (rank 0, N=1 only)
-plus "valu": the same kernel against the measured v_qsad_pk_u16_u8 issue rate, which is
-what actually bounds exhaustive search.
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      HBM view of the dominant kernel: algorithmic bytes / HIP-event kernel time, measured live
+  issue         the same kernel against its real bound, the VALU issue rate: busy fraction and
+                instructions per wave from the committed PMC profile of this command (labelled as such)
+  parity        the HIP results of >= 64 sampled pairs (first and last included) against the C oracle
+  content_sweep the same kernel on other content (real frames, noise, flat): pairs/s and the share of
+                candidate patches the elimination bound left for exact evaluation
+  cpu_baseline  the NumPy oracle (reference loop structure) on one host core over a bounded sample
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -55,6 +59,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # v_qsad_pk_u16_u8 issues one wave-instruction (64 lanes x 16 byte-abs-diffs) per ~16.3
 # cycles per SIMD at ~2.35 GHz -> 1024 SIMDs * 1024 ops / 6.9 ns
 QSAD_PEAK_OPS = 1024 * 1024 / 6.9e-9
+PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per bench line
+# rough C-oracle seconds per pair (one core), to size the parity sample
+ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.0, "exh1080mse": 1.2, "dia720": 0.01,
+                     "dia720mse": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15, "gme1080exh": 1.6}
 
 
 def algorithmic_bytes(H, W, bs, gme=False):
@@ -64,7 +72,7 @@ def algorithmic_bytes(H, W, bs, gme=False):
 
 
 def byte_ops_per_pair(H, W, bs, sw):
-    """Valid candidates x bs^2 (exact count of byte abs-diffs the exhaustive search needs)."""
+    """Valid candidates x bs^2 (exact count of byte abs-diffs a search that evaluates every candidate needs)."""
     def valid(n):
         tot = 0
         for o in range(0, n - bs + 1, bs):
@@ -73,34 +81,219 @@ def byte_ops_per_pair(H, W, bs, sw):
     return valid(H) * valid(W) * bs * bs
 
 
-def cpu_baseline(cfg, budget_s=14.0):
+def kernel_source_sha():
+    """Identity of the kernels a committed profile belongs to: sha256 over csrc/ sources."""
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "global-motion-estimation_amd", "csrc")
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(config):
+    """Counters of the newest committed PMC summary of `bench.py --config <config>` (profiles/), its
+    kernel_source_sha line and file name; ({}, None, None) if there is none."""
+    prof_dir = os.path.join(REPO, "profiles")
+    if not os.path.isdir(prof_dir):
+        return {}, None, None
+    cands = sorted(n for n in os.listdir(prof_dir) if n.endswith("_%s_pmc_summary.txt" % config))
+    if not cands:
+        return {}, None, None
+    vals, sha = {}, None
+    for line in open(os.path.join(prof_dir, cands[-1])):
+        if line.startswith("# kernel_source_sha:"):
+            sha = line.split(":", 1)[1].strip()
+        f = line.split()
+        if not line.startswith("#") and len(f) >= 4 and f[-1].startswith("mean=") and "k_exh_sea16p" in line:
+            vals[f[-3]] = float(f[-1].split("=")[1])
+    return vals, sha, cands[-1]
+
+
+# ---------------------------------------------------------------------------------------------
+# content other than the synthetic sequence (exhaustive configs): uint8[n, H, W] host stacks
+# ---------------------------------------------------------------------------------------------
+def host_content(kind, n, H, W):
+    g = os.path.join(REPO, "tests", "golden")
+    if kind == "noise":            # nothing correlates: the bound prunes (almost) nothing
+        rng = np.random.default_rng(99)
+        return rng.integers(0, 256, (n, H, W), dtype=np.uint8), H, W
+    if kind == "flat":             # all costs tie at zero
+        return np.full((n, H, W), 128, np.uint8), H, W
+    if kind == "race":             # the reference's 720x480 doc frames, alternating
+        z = np.load(os.path.join(g, "g3_docframes.npz"))
+        pair = [z["in_race_prev"], z["in_race_cur"]]
+        return np.stack([pair[i & 1] for i in range(n)]), 480, 720
+    if kind == "pan240seq":        # the reference's 51 real frames (320x240), walked back and forth
+        f = np.load(os.path.join(g, "g9_pan240seq.npz"))["frames"]
+        order = list(range(51)) + list(range(49, 0, -1))
+        return np.stack([f[order[i % len(order)]] for i in range(n)]), 240, 320
+    raise KeyError(kind)
+
+
+def sample_pairs(n_pairs, want):
+    want = max(2, min(want, n_pairs))
+    return sorted(set(int(round(x)) for x in np.linspace(0, n_pairs - 1, want)))
+
+
+def parity_sample_size(config):
+    return int(max(4, min(64, PARITY_BUDGET_S / ORACLE_S_PER_PAIR.get(config, 0.1))))
+
+
+def cpu_baseline_exhaustive(cfg, budget_s=14.0):
     """NumPy oracle on one core over whole block rows of pair (t=0, t=1) until `budget_s`."""
     H, W, bs, sw, proc, pnorm, seed, _ = cfg
     from oracle import gme_oracle
     import synth
     prev, cur = synth.frame(seed, 0, H, W), synth.frame(seed, 1, H, W)
-    nbr, nbc = H // bs, W // bs
-    mf = np.zeros((nbr, nbc, 2), np.int32)
+    nbr = H // bs
+    mf = np.zeros((nbr, W // bs, 2), np.int32)
     order = [nbr // 2] + [r for r in range(nbr) if r != nbr // 2]      # an interior row first
     done, t0 = [], time.perf_counter()
     for r in order:
-        if proc == 0:
-            gme_oracle.search_exhaustive(prev, cur, mf, H, W, pnorm, bs, sw, block_rows=(r, r + 1))
-        else:
-            strip = slice(r * bs, (r + 1) * bs)
-            raise NotImplementedError(strip)
+        gme_oracle.search_exhaustive(prev, cur, mf, H, W, pnorm, bs, sw, block_rows=(r, r + 1))
         done.append(r)
         if time.perf_counter() - t0 > budget_s:
             break
     el = time.perf_counter() - t0
-    # weight rows by their candidate count so that edge rows do not skew the extrapolation
-    def row_cands(r):
+
+    def row_cands(r):   # weight rows by their candidate count so that edge rows do not skew the extrapolation
         return sum(1 for w in range(-sw, sw + bs) if 0 <= r * bs + w <= H - bs)
     frac = sum(row_cands(r) for r in done) / sum(row_cands(r) for r in range(nbr))
     return {"value": frac / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": "oracle/gme_oracle.py (NumPy, reference loop structure) on %d of %d block rows of pair t=0,1 "
                       "(%.1f%% of the pair's candidates) in %.1f s" % (len(done), nbr, 100 * frac, el),
             "rows_checked": done, "mf": mf}
+
+
+def cpu_baseline_walk(cfg):
+    """NumPy oracle, one core, one whole pair of a walk search (diamond / three-step / 2-D log)."""
+    H, W, bs, sw, proc, pnorm, seed, _ = cfg
+    from oracle import gme_oracle
+    import synth
+    prev, cur = synth.frame(seed, 0, H, W), synth.frame(seed, 1, H, W)
+    t0 = time.perf_counter()
+    mf = gme_oracle.get_motion_field(prev, cur, block_size=bs, search_window=sw, searching_procedure=proc, pnorm_distance=pnorm)
+    el = time.perf_counter() - t0
+    return {"value": 1.0 / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "oracle/gme_oracle.py (NumPy, reference loop structure) on the whole pair t=0,1 in %.2f s" % el, "mf": mf}
+
+
+def cpu_baseline_gme(cfg, frames):
+    """NumPy oracle (reference loop structure), one core, one pair: motion.global_motion_estimation +
+    get_motion_field_affine + compensate_frame + PSNR (results.py:50-59,109).  For the exhaustive-search
+    GME of configs[3] only the two level searches are timed, on a bounded sample of block rows."""
+    H, W, bs, sw, proc, pnorm, seed, _ = cfg
+    from oracle import gme_oracle as o
+    prev, cur = frames
+    if proc == -2:
+        pp, cp = o.get_pyramids(prev), o.get_pyramids(cur)
+        total, parts = 0.0, []
+        for lvl, budget in ((2, 9.0), (1, 5.0)):
+            h, w = pp[lvl].shape
+            nbr = h // bs
+            mf = np.zeros((nbr, w // bs, 2), np.int32)
+            order = [nbr // 2] + [r for r in range(nbr) if r != nbr // 2]
+            done, t0 = 0, time.perf_counter()
+            for r in order:
+                o.search_exhaustive(pp[lvl], cp[lvl], mf, h, w, 1, bs, sw, block_rows=(r, r + 1))
+                done += 1
+                if time.perf_counter() - t0 > budget:
+                    break
+            el = time.perf_counter() - t0
+            total += el * nbr / done                       # interior rows: an upper-ish estimate of the level
+            parts.append("level %d: %d of %d block rows in %.1f s" % (lvl, done, nbr, el))
+        return {"value": 1.0 / total, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                "sample": "oracle/gme_oracle.py exhaustive MSE sw=%d level searches only, extrapolated from %s; pyramids, dense "
+                          "field, fits and compensation (seconds) not included" % (sw, "; ".join(parts))}
+    t0 = time.perf_counter()
+    params = o.global_motion_estimation(prev, cur)
+    field = o.affine_field((int(H / bs), int(W / bs)), params)
+    comp = o.compensate_frame(prev, field)
+    psnr = o.psnr(cur, comp)
+    el = time.perf_counter() - t0
+    return {"value": 1.0 / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "oracle/gme_oracle.py (NumPy, reference loop structure): GME + model field + compensation + PSNR of "
+                      "one pair in %.2f s" % el, "params": params, "psnr": psnr}
+
+
+class Comm:
+    """Barrier / max / gather across the ranks of one node.  world == 1: nothing.  world > 1: the
+    library's RCCL communicator (gme_comm_*: ncclAllReduce / ncclAllGather on the context's stream);
+    torch.distributed is the fallback transport if that cannot be brought up (and GME_BENCH_BACKEND=gloo
+    the CPU rehearsal)."""
+
+    def __init__(self, ctx, rank, world, local):
+        self.ctx, self.rank, self.world, self.kind, self.dist, self.torch = ctx, rank, world, "none", None, None
+        if world == 1 and not os.environ.get("GME_BENCH_FORCE_DIST"):
+            return
+        backend = os.environ.get("GME_BENCH_BACKEND", "rccl")
+        if backend == "rccl":
+            try:
+                import sequence
+                sequence.comm_init(ctx, rank, world)
+                self.kind = "rccl (C ABI: gme_comm_*)"
+                return
+            except Exception as e:          # noqa: BLE001 -- say so and fall back
+                print("bench.py: C-ABI RCCL communicator failed (%r); falling back to torch.distributed" % (e,), file=sys.stderr)
+                backend = "nccl"
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        # RCCL prints a version banner on stdout when it initialises; stdout must carry the one JSON
+        # line only, so park fd 1 on stderr until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+        self.kind = "torch.distributed/" + backend
+        self.device = torch.device("cuda", local) if backend == "nccl" else None
+
+    def barrier(self):
+        self.ctx.sync()
+        if self.kind.startswith("rccl"):
+            import sequence
+            sequence.comm_barrier(self.ctx)
+        elif self.dist is not None:
+            self.dist.barrier()
+            if self.torch.cuda.is_available():
+                self.torch.cuda.synchronize()
+
+    def max(self, value):
+        if self.kind.startswith("rccl"):
+            import sequence
+            return sequence.comm_max(self.ctx, value)
+        if self.dist is not None:
+            t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device or "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return value
+
+    def gather_rows(self, rows, n_pairs_total):
+        import sequence
+        if self.kind.startswith("rccl"):
+            return sequence.gather_parameters_rccl(self.ctx, rows, n_pairs_total, self.rank, self.world)
+        if self.dist is not None:
+            return sequence.gather_parameters(rows, n_pairs_total, self.rank, self.dist.get_world_size(), self.device)
+        return rows
+
+    def close(self):
+        if self.kind.startswith("rccl"):
+            import sequence
+            sequence.comm_destroy(self.ctx)
+        elif self.dist is not None:
+            self.dist.destroy_process_group()
 
 
 def main():
@@ -112,61 +305,36 @@ def main():
                     help="frame pairs resident and processed per step per GPU (default %d: launch ramps, tails and "
                          "the host-side solves of the GME stages cost the same per step whatever the batch)" % DEFAULT_PAIRS)
     ap.add_argument("--config", default="exh720", choices=sorted(CONFIGS))
+    ap.add_argument("--content", default="synthetic", choices=["synthetic", "race", "pan240seq", "noise", "flat"],
+                    help="frame content of the exhaustive / walk configs (uploaded from the host unless synthetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-content-sweep", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d does not match WORLD_SIZE=%d: launch it with torch.distributed.run "
+                 "--nproc-per-node %d (or plainly for --gpus 1)" % (args.gpus, world, args.gpus))
     cfg = CONFIGS[args.config]
     H, W, bs, sw, proc, pnorm, seed, label = cfg
-
-    import torch
-    dist = None
-    if world > 1 or os.environ.get("GME_BENCH_FORCE_DIST"):      # the latter rehearses RCCL with one rank
-        import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        local = local % max(ndev, 1)               # rehearsals may put several ranks on one card
-        torch.cuda.set_device(local)
-        backend = os.environ.get("GME_BENCH_BACKEND", "nccl")      # nccl = RCCL; gloo only for rehearsal
-        # RCCL prints a version banner on stdout when it initialises; stdout must carry the one
-        # JSON line only, so park fd 1 on stderr until the communicator exists
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-            dist.barrier()
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+    gme = proc < 0
+    if gme and args.content != "synthetic":
+        sys.exit("--content applies to the block-matching configs only")
 
     import _gme_native as native
-    ctx = native.Context(local)
+    ndev = native.load_library().gme_device_count()
+    ctx = native.Context(local % max(ndev, 1))          # rehearsals may put several ranks on one card
+    comm = Comm(ctx, rank, world, local % max(ndev, 1))
     B = args.pairs if args.pairs is not None else DEFAULT_PAIRS
-    gme = proc < 0
     # GME runs cut the resident pairs into `streams` ranges, each on its own HIP stream and host
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
     # not matter and concurrent persistent kernels only contend: 17.5 k pairs/s on one stream, 15 k on three)
     streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "3"))
-    shard = None
+    shard = seq = None
     if proc == -3:
         import sequence
         n_frames = int(os.environ.get("GME_BENCH_FRAMES", "2000"))
@@ -177,27 +345,27 @@ def main():
         import sequence
         shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams)
         shard.synth(seed, rank * B)                # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
-    else:
+    elif args.content == "synthetic":
         seq = native.Sequence(ctx, B + 1, H, W)
         seq.synth(seed, rank * B)
+    else:
+        frames, H, W = host_content(args.content, B + 1, H, W)
+        label = label.replace("synthetic luma", "%s content" % args.content).replace("720x480", "%dx%d" % (W, H))
+        seq = native.Sequence.from_frames(ctx, frames)
+        del frames
     if shard is not None:
         shard.sync()
     ctx.sync()
 
+    last = {}
     if proc == -3:
-        last = {}
-        gather_dev = torch.device("cuda", local) if (dist is not None and dist.get_backend() == "nccl") else None
-
         def step():
             shard.invalidate()
             params, psnr = shard.estimate_and_compensate()
             rows = np.concatenate([params, psnr[:, None]], axis=1)
-            if dist is not None:                   # the path's one exchange: 56 B per pair over RCCL
-                rows = sequence.gather_parameters(rows, shard.n_pairs_total, rank, dist.get_world_size(), gather_dev)
-            last["rows"] = rows
+            last["local_rows"] = rows
+            last["rows"] = comm.gather_rows(rows, shard.n_pairs_total)     # the path's one exchange: 56 B per pair
     elif gme:
-        last = {}
-
         def step():
             # motion.global_motion_estimation + results.py:52-59,109 for every resident pair;
             # frames change between videos, so the pyramids are rebuilt inside the step
@@ -208,8 +376,8 @@ def main():
                 last["params"], last["psnr"] = shard.estimate_and_compensate()
     else:
         def step():
-            # per-frame auxiliary tables (box sums for the pruning bound / the MSE identity) are
-            # derived from the frames: a new batch has to rebuild them, so every step does
+            # per-frame auxiliary tables (the MSE identity's box sums of squares) are derived from the
+            # frames: a new batch has to rebuild them, so every step does
             seq.invalidate_pyramids()
             seq.bbme(1, bs, sw, proc, pnorm)       # asynchronous launches on the context's stream
 
@@ -217,8 +385,7 @@ def main():
         step()
     if shard is not None:
         shard.sync()
-    ctx.sync()
-    barrier()
+    comm.barrier()
     ctx.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -226,123 +393,226 @@ def main():
     kernel_ms = ctx.timer_stop() / max(args.steps, 1)      # HIP events on the launch stream; synchronises
     if shard is not None:
         shard.sync()
-    ctx.sync()
-    barrier()
+    comm.barrier()
     elapsed = time.perf_counter() - t0
     if gme:
         kernel_ms = 1e3 * elapsed / max(args.steps, 1)     # several streams: the whole step on the wall clock
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = comm.max(elapsed)
 
-    # parity gate printed with the number: rank 0's first pair is the golden pair (seed 1234, t=0,1)
-    parity = None
-    mv = None if gme else seq.read_mv(0, 1)[0]
-    gpath = os.path.join(REPO, "tests", "golden", "g2_synth720.npz")
-    if rank == 0 and args.config in ("exh720", "exh720mse", "dia720", "dia720mse") and os.path.exists(gpath):
-        parity = bool(np.array_equal(mv, np.load(gpath)["mf_sp%d_pn%d" % (proc, pnorm)]))
-    if rank == 0 and args.config == "gme720":
-        g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_gme.npz"))
-        import hashlib
-        comp_sha = hashlib.sha256(shard.read_compensated(0).tobytes()).hexdigest()
-        parity = bool(np.allclose(last["params"][0], g4["synth720_params"], rtol=1e-10, atol=1e-12)
-                      and comp_sha == str(g4["synth720_comp_sha"]))
+    if rank != 0:
+        comm.close()
+        return
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import c_oracle, oracle_results_flow
 
-    if rank == 0:
-        total_pairs = (shard.n_pairs_total if proc == -3 else world * B) * args.steps
-        value = total_pairs / elapsed
-        abytes = algorithmic_bytes(H, W, bs, gme) * B
-        if proc == -3:
+    # ---- parity gate printed with the number: sampled pairs (first and last included) against the C oracle
+    n_s = parity_sample_size(args.config)
+    parity = {"checker": "oracle/gme_oracle.c (C restatement pinned on the reference's goldens)"}
+    t_par = time.perf_counter()
+    if not gme:
+        info = ctx.last_bbme_info()
+        co = c_oracle()
+        idx = sample_pairs(B, n_s)
+        bad = []
+        for p in idx:
+            got = seq.read_mv(p, 1)[0]
+            if not np.array_equal(got, co.bbme(seq.read_frame(p), seq.read_frame(p + 1), bs, sw, proc, pnorm)):
+                bad.append(p)
+        parity.update({"pairs_checked": len(idx), "first": idx[0], "last": idx[-1], "mismatching_pairs": bad, "ok": not bad,
+                       "what": "motion-vector field, bit-exact"})
+        gpath = os.path.join(REPO, "tests", "golden", "g2_synth720.npz")
+        if args.config in ("exh720", "exh720mse", "dia720", "dia720mse") and args.content == "synthetic" and os.path.exists(gpath):
+            parity["pair0_equals_reference_golden"] = bool(np.array_equal(seq.read_mv(0, 1)[0], np.load(gpath)["mf_sp%d_pn%d" % (proc, pnorm)]))
+            parity["ok"] = parity["ok"] and parity["pair0_equals_reference_golden"]
+    else:
+        info = shard.lanes[0].ctx.last_bbme_info()
+        n_local = shard.n_pairs
+        idx = sample_pairs(n_local, n_s)
+        params = last["local_rows"][:, :6] if proc == -3 else last["params"]
+        psnr = last["local_rows"][:, 6] if proc == -3 else last["psnr"]
+        bad = []
+        worst = 0.0
+        for p in idx:
+            lane, k = shard._lane_of(p)
+            f0, f1 = lane.seq.read_frame(k), lane.seq.read_frame(k + 1)
+            wp, _, wc, wpsnr = oracle_results_flow(f0, f1, bs, 0 if proc == -2 else 3, sw if proc == -2 else 2)
+            ok = (np.allclose(params[p], wp, rtol=1e-10, atol=1e-12) and np.array_equal(shard.read_compensated(p), wc)
+                  and abs(psnr[p] - wpsnr) < 1e-9)
+            worst = max(worst, float(np.max(np.abs(params[p] - wp))))
+            if not ok:
+                bad.append(p)
+        parity.update({"pairs_checked": len(idx), "first": idx[0], "last": idx[-1], "mismatching_pairs": bad, "ok": not bad,
+                       "what": "parameters (rtol 1e-10), compensated frame (bit-exact), PSNR (1e-9 dB)",
+                       "max_abs_param_diff": worst})
+        if proc == -3 and world > 1:            # gathered rows of the other ranks: the frames come from the host generator
+            import synth
             rows = last["rows"]
-            out_extra = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),
-                         "mean_psnr_db": float(np.mean(rows[:, 6])),
-                         "median_params": [float(x) for x in np.median(rows[:, :6], axis=0)]}
-        achieved = abytes / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive, 1->8 GPU"
-                      if args.config == "exh720" else "frame-pairs/s, " + args.config,
-            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if proc == -3 else "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
-                       "sharding": "frame pairs across ranks, no data-path collective",
-                       "streams_per_gpu": len(shard.lanes) if shard is not None else 1},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_exh_sea16p<3, 6>" if (proc, pnorm, bs, sw) == (0, 0, 16, 16) else
-                                   ("whole step (all kernels + host solves)" if gme else "see DESIGN.md"),
-                         "kernel_ms_per_launch": kernel_ms,
-                         "algorithmic_bytes_per_launch": abytes},
-            "parity_first_pair_vs_reference_golden": parity,
-        }
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) KB, the x2 being the guide's gfx950
-        # FETCH_SIZE correction, which the L2 miss count (TCC_MISS x 128 B) confirms here.
-        prof = os.path.join(REPO, "profiles", "r01_final_exh720_pmc_summary.txt")
-        if args.config == "exh720" and B == DEFAULT_PAIRS and os.path.exists(prof):    # the profile is of the default command
-            vals = {}
-            for line in open(prof):
-                f = line.split()
-                for name in ("FETCH_SIZE", "WRITE_SIZE"):
-                    if name in f and not line.startswith("#"):
-                        vals[name] = float(f[-1].split("=")[1])
-            if len(vals) == 2:
-                out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-                out["roofline"]["traffic_unit"] = "bytes per launch, from profiles/r01_final_exh720_pmc_summary.txt"
-        if proc == 0:
-            ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
-            # brute-force-equivalent rate: the exhaustive search's nominal byte abs-diffs per second.
-            # With exact successive elimination most candidates are never evaluated, so this may
-            # exceed the instruction-issue ceiling of a brute-force kernel (frac > 1).
-            out["valu"] = {"bound": "v_qsad_pk_u16_u8 issue (brute-force equivalent)", "achieved": ops,
-                           "peak": QSAD_PEAK_OPS, "unit": "byte-abs-diff/s", "frac": ops / QSAD_PEAK_OPS}
-        if proc >= 0 and world == 1:
-            # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
-            # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
-            n_e2e = B                                              # same launch size as the timed steps: a profile of
-                                                                   # this command averages like-sized launches only
-            host_frames = np.stack([seq.read_frame(i) for i in range(n_e2e + 1)])
-            seq2 = native.Sequence(ctx, n_e2e + 1, H, W)          # its own small sequence: upload, search, read back
-            seq2.upload(0, host_frames[:2])                        # first touch of the buffers outside the timing
+            other = [p for p in sample_pairs(shard.n_pairs_total, 5) if not (shard.pair_start <= p < shard.pair_stop)]
+            for p in other:
+                wp, _, _, wpsnr = oracle_results_flow(synth.frame(seed, p, H, W), synth.frame(seed, p + 1, H, W), bs)
+                if not (np.allclose(rows[p, :6], wp, rtol=1e-10, atol=1e-12) and abs(rows[p, 6] - wpsnr) < 1e-9):
+                    bad.append(p)
+            parity.update({"gathered_pairs_of_other_ranks_checked": other, "mismatching_pairs": bad, "ok": not bad})
+        if args.config == "gme720":
+            g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_gme.npz"))
+            comp_sha = hashlib.sha256(shard.read_compensated(0).tobytes()).hexdigest()
+            parity["pair0_equals_reference_golden"] = bool(np.allclose(last["params"][0], g4["synth720_params"], rtol=1e-10, atol=1e-12)
+                                                           and comp_sha == str(g4["synth720_comp_sha"]))
+            parity["ok"] = parity["ok"] and parity["pair0_equals_reference_golden"]
+    parity["seconds"] = round(time.perf_counter() - t_par, 2)
+
+    total_pairs = (shard.n_pairs_total if proc == -3 else world * B) * args.steps
+    value = total_pairs / elapsed
+    abytes = algorithmic_bytes(H, W, bs, gme) * B
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive"
+                  if args.config == "exh720" else "frame-pairs/s, " + args.config,
+        "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if proc == -3 else "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.content == "synthetic" else args.content,
+        "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
+                   "sharding": "frame pairs across ranks, no data-path collective",
+                   "streams_per_gpu": len(shard.lanes) if shard is not None else 1,
+                   "collective": comm.kind, "multi_gpu_measured_by_builder": False},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": info["plan"] if not gme else "whole step (all kernels + host solves)",
+                     "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": abytes},
+        "parity": parity,
+    }
+    if info.get("patches"):
+        out["elimination"] = {"patches": info["patches"], "surviving": info["surviving"],
+                              "surviving_fraction": info["surviving"] / info["patches"]}
+
+    # ---- HBM traffic and issue statistics of the dominant kernel from the committed rocprofv3 PMC passes of
+    # this same command (profiles/): valid only for the kernels they were taken from (kernel_source_sha)
+    vals, psha, pname = committed_profile(args.config)
+    switches = sorted(k for k in os.environ if k.startswith("GME_") and k not in ("GME_DEVICE",))
+    if proc == 0:
+        ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
+        out["brute_force_equivalent"] = {
+            "note": "byte abs-diffs a search that evaluates EVERY candidate would need, per second; the elimination kernel "
+                    "never evaluates most of them, so this is not a utilisation figure (it may exceed the QSAD issue peak)",
+            "value": ops, "unit": "byte-abs-diff/s", "qsad_issue_peak": QSAD_PEAK_OPS}
+    if vals and args.content == "synthetic":
+        reason = None
+        if psha != kernel_source_sha():
+            reason = "kernel sources changed since %s was taken" % pname
+        elif switches:
+            reason = "runtime switches set: " + ",".join(switches)
+        elif B != DEFAULT_PAIRS or world != 1:
+            reason = "profile is of the default single-GPU command"
+        if reason is None and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+            out["roofline"]["traffic_source"] = ("committed profile profiles/%s: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
+                                                 "x2 = the guide's gfx950 FETCH_SIZE correction" % pname)
+        else:
+            out["roofline"]["traffic_source"] = "null: " + (reason or "no FETCH_SIZE/WRITE_SIZE in the committed profile")
+        if reason is None and all(k in vals for k in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+                                                      "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")):
+            cyc = vals["GRBM_GUI_ACTIVE"] / 8.0                 # summed over the 8 XCDs
+            wave_tiles = info["patches"] / (64 * ((2 * sw + 16 + 15) // 16)) if info.get("patches") else None
+            out["issue"] = {
+                "bound": "valu_issue", "source": "committed profile profiles/%s (same kernel sources, same command)" % pname,
+                "achieved": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), "peak": 1.0, "unit": "VALU-busy fraction of SIMD cycles",
+                "frac": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc),
+                "salu_per_valu_inst": vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"],
+                "lds_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"],
+                "insts_per_wave_tile": None if not wave_tiles else {"valu": vals["SQ_INSTS_VALU"] / wave_tiles,
+                                                                    "salu": vals["SQ_INSTS_SALU"] / wave_tiles,
+                                                                    "lds": vals["SQ_INSTS_LDS"] / wave_tiles}}
+
+    # ---- the same kernel on other content: real frames, noise (no pruning), flat (all ties)
+    if proc == 0 and world == 1 and args.content == "synthetic" and not args.no_content_sweep:
+        sweep = {}
+        nsw = min(B, 512)
+        for kind in ("race", "pan240seq", "noise", "flat"):
+            if kind == "race" and (H, W) != (480, 720):
+                continue
+            fr, h2, w2 = host_content(kind, nsw + 1, H, W)
+            s2 = native.Sequence.from_frames(ctx, fr)
+            s2.bbme(1, bs, sw, proc, pnorm)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(3):
+                s2.invalidate_pyramids()
+                s2.bbme(1, bs, sw, proc, pnorm)
+            ms = ctx.timer_stop() / 3
+            inf = ctx.last_bbme_info()
+            co = c_oracle()
+            chk = sample_pairs(nsw, 6)
+            ok = all(np.array_equal(s2.read_mv(p, 1)[0], co.bbme(fr[p], fr[p + 1], bs, sw, proc, pnorm)) for p in chk)
+            sweep[kind] = {"frame": "%dx%d" % (w2, h2), "pairs": nsw, "pairs_per_s": nsw / (ms * 1e-3), "kernel": inf["plan"].split(" grid")[0],
+                           "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
+                           "parity_ok_sampled": bool(ok)}
+            s2.close()
+        out["content_sweep"] = sweep
+
+    if proc >= 0 and world == 1 and not args.no_pcie:
+        # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
+        # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
+        n_e2e = B
+        host_frames = np.stack([seq.read_frame(i) for i in range(n_e2e + 1)])
+        seq2 = native.Sequence(ctx, n_e2e + 1, H, W)          # its own sequence: upload, search, read back
+        pipelined = hasattr(seq2, "bbme_streamed")
+        if pipelined:
+            seq2.bbme_streamed(host_frames[:min(65, n_e2e + 1)], 1, bs, sw, proc, pnorm)     # first touch outside the timing
+            ctx.sync()
+            t_e = time.perf_counter()
+            mv2 = seq2.bbme_streamed(host_frames, 1, bs, sw, proc, pnorm)
+            t_e = time.perf_counter() - t_e
+        else:
+            seq2.upload(0, host_frames[:2])
             ctx.sync()
             t_e = time.perf_counter()
             seq2.upload(0, host_frames)
             seq2.bbme(1, bs, sw, proc, pnorm)
-            _ = seq2.read_mv(0, n_e2e)
+            mv2 = seq2.read_mv(0, n_e2e)
             t_e = time.perf_counter() - t_e
-            seq2.close()
-            out["pcie_inclusive"] = {"value": n_e2e / t_e, "unit": "frame-pairs/s",
-                                     "note": "upload of %d frames from pageable host memory + search + read-back of %d fields; "
-                                             "each frame crosses once" % (n_e2e + 1, n_e2e)}
-        if proc == -3:
-            out["sequence"] = out_extra
-        if world == 1 and not args.no_cpu_baseline and proc == 0:
-            cb = cpu_baseline(cfg)
-            rows, ref_mf = cb.pop("rows_checked"), cb.pop("mf")
-            cb["matches_gpu"] = bool(all(np.array_equal(ref_mf[r], mv[r]) for r in rows))
-            out["cpu_baseline"] = cb
+        same = bool(np.array_equal(mv2[-1], seq.read_mv(B - 1, 1)[0]) and np.array_equal(mv2[0], seq.read_mv(0, 1)[0]))
+        seq2.close()
+        out["pcie_inclusive"] = {"value": n_e2e / t_e, "unit": "frame-pairs/s", "equals_resident_result": same,
+                                 "note": ("chunked upload of %d frames through a pinned staging ring on a copy stream, overlapped with the "
+                                          "search of the previous chunk, + read-back of %d fields" if pipelined else
+                                          "upload of %d frames from pageable host memory + search + read-back of %d fields; "
+                                          "each frame crosses once") % (n_e2e + 1, n_e2e)}
+    if proc == -3:
+        rows = last["rows"]
+        out["sequence"] = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),
+                           "mean_psnr_db": float(np.mean(rows[:, 6])),
+                           "median_params": [float(x) for x in np.median(rows[:, :6], axis=0)]}
+    if world == 1 and not args.no_cpu_baseline and args.content == "synthetic":
+        if proc == 0:
+            cb = cpu_baseline_exhaustive(cfg)
+            rows_c, ref_mf = cb.pop("rows_checked"), cb.pop("mf")
+            mv0 = seq.read_mv(0, 1)[0]
+            cb["matches_gpu"] = bool(all(np.array_equal(ref_mf[r], mv0[r]) for r in rows_c))
+        elif proc > 0:
+            cb = cpu_baseline_walk(cfg)
+            cb["matches_gpu"] = bool(np.array_equal(cb.pop("mf"), seq.read_mv(0, 1)[0]))
+        else:
+            lane = shard.lanes[0]
+            cb = cpu_baseline_gme(cfg, (lane.seq.read_frame(0), lane.seq.read_frame(1)))
+            if "params" in cb:
+                p0 = last["local_rows"][0, :6] if proc == -3 else last["params"][0]
+                ps0 = last["local_rows"][0, 6] if proc == -3 else last["psnr"][0]
+                cb["matches_gpu"] = bool(np.allclose(cb.pop("params"), p0, rtol=1e-10, atol=1e-12) and abs(cb.pop("psnr") - ps0) < 1e-9)
+        out["cpu_baseline"] = cb
+        if proc == 0:
             # BASELINE.md §3 "optimised CPU": the integer C oracle (gcc -O3, one core) on the same
             # pair, so the GPU figure is not only measured against interpreter overhead
-            try:
-                sys.path.insert(0, os.path.join(REPO, "tests"))
-                from helpers import c_oracle
-                import synth
-                p0, p1 = synth.frame(seed, 0, H, W), synth.frame(seed, 1, H, W)
-                co = c_oracle()
-                t_c = time.perf_counter()
-                mf_c = co.bbme(p0, p1, bs, sw, proc, pnorm)
-                t_c = time.perf_counter() - t_c
-                out["cpu_baseline_c"] = {"value": 1.0 / t_c, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-                                         "sample": "oracle/gme_oracle.c (integer C, gcc -O3) on the whole pair t=0,1 in %.2f s" % t_c,
-                                         "matches_gpu": bool(np.array_equal(mf_c, mv))}
-            except Exception as e:      # the C oracle is optional test infrastructure
-                out["cpu_baseline_c"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+            co = c_oracle()
+            p0, p1 = seq.read_frame(0), seq.read_frame(1)
+            t_c = time.perf_counter()
+            mf_c = co.bbme(p0, p1, bs, sw, proc, pnorm)
+            t_c = time.perf_counter() - t_c
+            out["cpu_baseline_c"] = {"value": 1.0 / t_c, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                     "sample": "oracle/gme_oracle.c (integer C, gcc -O3) on the whole pair t=0,1 in %.2f s" % t_c,
+                                     "matches_gpu": bool(np.array_equal(mf_c, seq.read_mv(0, 1)[0]))}
+    print(json.dumps(out), flush=True)
+    comm.close()
 
 
 if __name__ == "__main__":

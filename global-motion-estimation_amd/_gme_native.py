@@ -44,6 +44,7 @@ _SIGNATURES = {
     "gme_sync": (_i, [_vp]),
     "gme_stream": (_vp, [_vp]),
     "gme_device_info": (_i, [_vp, ctypes.c_char_p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "gme_last_bbme_info": (_i, [_vp, ctypes.c_char_p, _i, _c_i64p, _c_i64p]),
     "gme_timer_start": (_i, [_vp]),
     "gme_timer_stop": (_i, [_vp, _c_f32p]),
     "gme_bbme_u8": (_i, [_vp, _c_u8p, _c_u8p, _i, _i, _i, _i, _i, _i, _i, _c_i32p]),
@@ -59,6 +60,14 @@ _SIGNATURES = {
     "gme_seq_invalidate": (_i, [_vp]),
     "gme_seq_bbme": (_i, [_vp, _i, _i, _i, _i, _i]),
     "gme_seq_read_mv": (_i, [_vp, _i, _i, _c_i32p]),
+    "gme_seq_bbme_streamed": (_i, [_vp, _c_u8p, _i, ctypes.c_int64, _i, _i, _i, _i, _i, _i, _i, _c_i32p]),
+    "gme_host_alloc": (_vp, [ctypes.c_size_t]),
+    "gme_host_free": (None, [_vp]),
+    "gme_comm_unique_id": (_i, [ctypes.c_char_p]),
+    "gme_comm_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "gme_comm_destroy": (_i, [_vp]),
+    "gme_shard_gather": (_i, [_vp, _c_f64p, _i, _i, _i, _c_f64p]),
+    "gme_comm_allreduce_max": (_i, [_vp, _c_f64p, _i]),
     "gme_seq_gme_begin": (_i, [_vp, _i, _i, _i, _i, _c_f32p]),
     "gme_seq_gme_fit": (_i, [_vp, _i, _c_f64p, ctypes.c_double, _c_f64p]),
     "gme_seq_gme_read_stage": (_i, [_vp, _i, _i, _c_i32p, _c_i16p, _c_u8p, _c_i64p]),
@@ -128,6 +137,44 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+def _block_size(bs):
+    """The reference divides the frame shape by the block size first (bbme.py:23-25, motion.py:303):
+    a zero block size is a ZeroDivisionError there, before anything else is looked at."""
+    bs = int(bs)
+    if bs == 0:
+        raise ZeroDivisionError("division by zero")
+    return bs
+
+
+class _Pinned:
+    """Owner of one gme_host_alloc block; frees it when the last array view goes away."""
+
+    def __init__(self, lib, nbytes):
+        self.lib, self.ptr = lib, lib.gme_host_alloc(nbytes)
+        if not self.ptr:
+            raise MemoryError((lib.gme_last_error() or b"").decode())
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.gme_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """np.empty in page-locked host memory (gme_host_alloc): frame loaders that decode into it let
+    uploads run at link speed and overlap the kernels (Sequence.bbme_streamed, ShardedSequence.load)."""
+    lib = load_library()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    owner = _Pinned(lib, max(n, 1))
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(owner.ptr)
+    buf._gme_owner = owner                     # the array's .base chain keeps `buf`, which keeps the block
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class Context:
     """One device + one HIP stream (gme_ctx)."""
 
@@ -167,6 +214,14 @@ class Context:
         _check(self.lib.gme_device_info(self.handle, name, 128, ctypes.byref(cu), ctypes.byref(clk)), self.lib)
         return {"name": name.value.decode(), "cu_count": cu.value, "clock_khz": clk.value}
 
+    def last_bbme_info(self):
+        """{'plan': kernel / tile shape / schedule of the last block-matching call,
+        'patches': candidate patches its elimination bound saw, 'surviving': those left for exact evaluation}."""
+        plan = ctypes.create_string_buffer(192)
+        n, k = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self.lib.gme_last_bbme_info(self.handle, plan, 192, ctypes.byref(n), ctypes.byref(k)), self.lib)
+        return {"plan": plan.value.decode(), "patches": n.value, "surviving": k.value}
+
     def timer_start(self):
         _check(self.lib.gme_timer_start(self.handle), self.lib)
 
@@ -181,6 +236,7 @@ class Context:
         if prev.shape != cur.shape:
             raise AssertionError("previous and current differ in shape (bbme.py:59)")
         H, W = prev.shape
+        block_size = _block_size(block_size)
         if cur.strides[0] != prev.strides[0]:
             cur = np.ascontiguousarray(cur)
             prev = np.ascontiguousarray(prev)
@@ -290,8 +346,26 @@ class Sequence:
 
     # ---- BBME over all pairs
     def bbme(self, frame_distance, block_size, search_window, procedure, pnorm):
+        block_size = _block_size(block_size)
         _check(self.lib.gme_seq_bbme(self.handle, frame_distance, block_size, search_window, procedure, pnorm), self.lib)
         self._mv_shape = (self.N - frame_distance, int(self.H / block_size), int(self.W / block_size), 2)
+
+    def bbme_streamed(self, frames, frame_distance, block_size, search_window, procedure, pnorm, chunk_frames=128):
+        """bbme() for frames that still live in host memory (uint8[n, H, W], n <= N): chunked upload on a
+        copy stream overlapped with the search of the previous chunk -> int32[n - fd, h, w, 2]."""
+        block_size = _block_size(block_size)
+        frames = np.asarray(frames)
+        if frames.ndim != 3 or frames.dtype != np.uint8 or frames.shape[1:] != (self.H, self.W):
+            raise TypeError("frames must be uint8[n, %d, %d]" % (self.H, self.W))
+        if frames.strides[2] != 1 or frames.strides[1] < self.W or frames.strides[0] < frames.strides[1] * self.H:
+            frames = np.ascontiguousarray(frames)
+        n = frames.shape[0]
+        out = np.empty((max(n - frame_distance, 0), int(self.H / block_size), int(self.W / block_size), 2), dtype=np.int32)
+        _check(self.lib.gme_seq_bbme_streamed(self.handle, _p(frames, _c_u8p), frames.strides[1], frames.strides[0], n,
+                                              frame_distance, block_size, search_window, procedure, pnorm, int(chunk_frames),
+                                              _p(out, _c_i32p)), self.lib)
+        self._mv_shape = out.shape
+        return out
 
     def read_mv(self, first=0, count=None):
         pairs = self._mv_shape[0]
@@ -304,6 +378,7 @@ class Sequence:
     # ---- GME stages
     def gme_begin(self, frame_distance, bbme_block_size, procedure=3, search_window=2):
         pairs = self.N - frame_distance
+        bbme_block_size = _block_size(bbme_block_size)
         p0 = np.empty((max(pairs, 0), 6), dtype=np.float32)
         _check(self.lib.gme_seq_gme_begin(self.handle, frame_distance, bbme_block_size, procedure, search_window,
                                           _p(p0, _c_f32p)), self.lib)
@@ -342,6 +417,7 @@ class Sequence:
     # ---- compensation + squared error
     def compensate(self, frame_distance, block_size, params):
         pairs = self.N - frame_distance
+        block_size = _block_size(block_size)
         p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(pairs, 6))
         sse = np.empty(pairs, dtype=np.int64)
         _check(self.lib.gme_seq_compensate(self.handle, frame_distance, block_size, _p(p, _c_f64p), _p(sse, _c_i64p)),

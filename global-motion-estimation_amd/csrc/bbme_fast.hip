@@ -434,6 +434,7 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const long long groups = (long long)((job.pairs + 7) / 8) * 8 * d.wg_per_pair;
     GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
     const dim3 grid((unsigned)groups), block(64 * nb);
+    plan_note(ctx, 0, "%s<%d> 1x%d blocks per workgroup grid %lld", mse ? "k_exh_dot16" : "k_exh_qsad16", R, nb, groups);
     if (mse) {
         switch (R) {
         case 1: hipLaunchKernelGGL(k_exh_dot16<1>, grid, block, lds, ctx->stream, d); break;

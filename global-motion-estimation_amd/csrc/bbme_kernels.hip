@@ -334,6 +334,11 @@ int launch_bbme(gme_ctx* ctx, const BbmeJob& job)
     // long sequences: keep every launch below ~16 M blocks so grid sizes stay far from 2^31
     const long long nblk = (long long)(job.H / job.bs) * (job.W / job.bs);
     if (nblk == 0 || job.pairs == 0) return GME_OK;
+    if (!job.chained) {
+        ctx->plan[0] = 0;
+        ctx->plan_patches = 0;
+        GME_HIP_TRY(hipMemsetAsync(ctx->status + GME_STATUS_STATS, 0, 8 * 16 * sizeof(int), ctx->stream));
+    }
     long long cap = 1ll << 24;
     if (const char* e = getenv("GME_BBME_CHUNK_BLOCKS")) {             // test hook: reach the chunked path with few pairs
         const long long v = atoll(e);
@@ -382,6 +387,7 @@ static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
     d.status = ctx->status;
 
     if (job.procedure == GME_SEARCH_EXHAUSTIVE) {
+        plan_note(ctx, 0, "k_exh_generic%s grid %lld", d.f32 ? " (float32-order costs)" : "", nblk * job.pairs);
         hipLaunchKernelGGL(k_exh_generic, dim3((unsigned)(nblk * job.pairs)), dim3(256), 0, ctx->stream, d);
     } else {
         const int px = job.bs * job.bs;
@@ -389,6 +395,7 @@ static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
         const int G = d.f32 ? 1 : px <= 4 ? 1 : px <= 16 ? 4 : px <= 64 ? 16 : 64;
         const long long threads = nblk * job.pairs * G;
         const unsigned grid = (unsigned)((threads + 255) / 256);
+        plan_note(ctx, 0, "k_walk<%d>%s grid %u", G, d.f32 ? " (float32-order costs)" : "", grid);
         switch (G) {
         case 1: hipLaunchKernelGGL(k_walk<1>, dim3(grid), dim3(256), 0, ctx->stream, d); break;
         case 4: hipLaunchKernelGGL(k_walk<4>, dim3(grid), dim3(256), 0, ctx->stream, d); break;

@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     __syncthreads();
     STAMP(2);
     MaeTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
+    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
 }
 
 template <int R, int NV>
@@ -414,6 +415,7 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
     d.tile_ctr = nullptr;
+    d.stats = (uint32_t*)ctx->status + GME_STATUS_STATS;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
@@ -431,9 +433,11 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const bool fits = R <= 1 || R >= 4 || nv <= 8;
     if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
+        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p<%d,%d> tiles %dx%d persistent-%s grid %u lds %zu",
+                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", grid.x, lds);
         d.tile_ctr = nullptr;
         if (pp.dynamic) {
-            d.tile_ctr = (uint32_t*)ctx->status + 64;
+            d.tile_ctr = (uint32_t*)ctx->status + GME_STATUS_TILECTR;
             GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
 #define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p<RR, NVV>), grid, block, lds, ctx->stream, d)
@@ -451,6 +455,8 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     } else {
     dim3 grid;
     GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+    plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16<%d> tiles %dx%d one-tile grid %ux%ux%u lds %zu", R, d.tr, d.tc,
+              grid.x, grid.y, grid.z, lds);
     // phase E with four lanes per patch (a quarter of the latency the other waves wait for): +11 % at
     // sw 32, +3 % at sw 16 in the persistent kernel; GME_SEA_E4 = 0 / 1 overrides it for this one-tile kernel
     const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : R >= 3;

@@ -31,6 +31,7 @@ struct SeaDev {
     unsigned long long magic_wpp; // persistent kernel: n / wg_per_pair == (n * magic_wpp) >> 40 for n < 2^21
     unsigned long long magic_wpr; // same for n / wg_per_row
     uint32_t* tile_ctr;           // persistent kernel, dynamic schedule: one counter per XCD, 16 words apart (or null)
+    uint32_t* stats;              // per XCD, 16 words apart: [0] patches the bound left for exact evaluation (phase D's list)
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
     const uint32_t* sqbox;        // MSE only: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
@@ -107,8 +108,8 @@ __host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int p
     l.win = 0;
     l.anchor = (win_rows * pitch_dw + 3) & ~3;         // 16-byte aligned: anchor rows are read as b128
     l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
-    l.count = l.best + 2 * nb;
-    l.a2 = l.count + 2;
+    l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [2] list lengths of earlier tiles
+    l.a2 = l.count + 4;
     l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [s8_rows][xq] u16x4
     l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
     l.total = l.work + nb * 64 * R;
@@ -371,6 +372,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
     uint32_t* ctr = d.tile_ctr ? d.tile_ctr + 16 * xcd : nullptr;
     uint32_t drawn = 0;
     if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 2] = 0; }
     for (;;) {
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -389,6 +391,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         const uint32_t mine = an_next;
         const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, wave_block(d, trow_c, bcol0_c, wave).ok, mine);
         if (tid == 0) {
+            lds[L.count + 2] += lds[L.count];              // the finished tile's list length (statistics)
             lds[L.count] = 0;
             if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
         }
@@ -403,6 +406,8 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         if (!more) break;
         __syncthreads();                                   // everyone is done with this tile's LDS
     }
+    // thread 0 has passed the barrier behind phase D: the last tile's list length is final
+    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * xcd, lds[L.count + 2] + lds[L.count]);
 }
 
 // Host side of the persistent form: resident workgroups per XCD (what LDS and the 32 wave slots of

@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     if (threadIdx.x == 0) lds[L.count] = 0;
     __syncthreads();
     MseTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
+    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
 }
 
 template <int R, int NV>
@@ -329,6 +330,7 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
     d.tile_ctr = nullptr;
+    d.stats = (uint32_t*)ctx->status + GME_STATUS_STATS;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
@@ -347,8 +349,10 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const bool fits = R != 3 || nv <= 12;
     if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
+        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p_mse<%d,%d> tiles %dx%d persistent-%s grid %u lds %zu",
+                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", grid.x, lds);
         if (pp.dynamic) {
-            d.tile_ctr = (uint32_t*)ctx->status + 64;
+            d.tile_ctr = (uint32_t*)ctx->status + GME_STATUS_TILECTR;
             GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
 #define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p_mse<RR, NVV>), grid, block, lds, ctx->stream, d)
@@ -366,6 +370,8 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     } else {
         dim3 grid;
         GME_REQUIRE(grid_for(d, &grid), GME_ERR_ARG, "too many workgroups in one launch");
+    plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16_mse<%d> tiles %dx%d one-tile grid %ux%ux%u lds %zu", R, d.tr, d.tc,
+              grid.x, grid.y, grid.z, lds);
         const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : false;   // measured: four lanes per patch lose 9 % here (repeated v_alignbyte work)
 #define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16_mse<RR, true>), grid, block, lds, ctx->stream, d); \
                             else hipLaunchKernelGGL((k_exh_sea16_mse<RR, false>), grid, block, lds, ctx->stream, d); } while (0)

@@ -442,10 +442,12 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         const long long groups = (long long)((job.pairs + 7) / 8) * 8 * wpp;
         GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
         const unsigned grid = (unsigned)groups;
+        plan_note(ctx, 0, "k_walk16<%d> grid %u", job.pnorm, (unsigned)grid);
         if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
         else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
         const unsigned grid = (unsigned)((total + 255) / 256);
+        plan_note(ctx, 0, "k_dense2<%d> grid %u", job.pnorm, (unsigned)grid);
         if (job.pnorm == 0) hipLaunchKernelGGL(k_dense2<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
         else hipLaunchKernelGGL(k_dense2<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
     } else {

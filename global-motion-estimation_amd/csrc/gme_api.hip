@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "gme_internal.h"
 
@@ -19,6 +20,17 @@ void gme_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* gme_last_error(void) { return g_err; }
+
+// first chunk of a block-matching call names the plan, later chunks only add their patches
+void plan_note(gme_ctx* ctx, long long patches, const char* fmt, ...)
+{
+    ctx->plan_patches += patches;
+    if (ctx->plan[0]) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->plan, sizeof(ctx->plan), fmt, ap);
+    va_end(ap);
+}
 
 extern "C" int gme_device_count(void)
 {
@@ -43,8 +55,8 @@ extern "C" gme_ctx* gme_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void**)&ctx->status, 1024) != hipSuccess ||
-        hipMemsetAsync(ctx->status, 0, 1024, ctx->stream) != hipSuccess ||
+        hipMalloc((void**)&ctx->status, GME_STATUS_WORDS * sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(ctx->status, 0, GME_STATUS_WORDS * sizeof(int), ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         gme_set_error("gme_create: HIP initialisation failed on device %d: %s", device_id,
                       hipGetErrorString(hipGetLastError()));
@@ -72,10 +84,13 @@ extern "C" void gme_destroy(gme_ctx* ctx)
 {
     if (!ctx) return;
     { std::lock_guard<std::mutex> lock(ctx->mu); }        // let a call in flight on another thread finish
+    gme_comm_destroy(ctx);
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->status) hipFree(ctx->status);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->back_stream) hipStreamDestroy(ctx->back_stream);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipStreamDestroy(ctx->stream);
@@ -110,6 +125,22 @@ extern "C" int gme_sync(gme_ctx* ctx)
 {
     GME_ENTER(ctx);
     return ctx_finish(ctx);
+}
+
+extern "C" int gme_last_bbme_info(gme_ctx* ctx, char* plan, int plan_len, int64_t* patches, int64_t* surviving)
+{
+    GME_ENTER(ctx);
+    if (plan && plan_len > 0) snprintf(plan, plan_len, "%s", ctx->plan);
+    if (patches) *patches = ctx->plan_patches;
+    if (surviving) {
+        uint32_t st[8 * 16];
+        GME_HIP_TRY(hipMemcpyAsync(st, ctx->status + GME_STATUS_STATS, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int64_t n = 0;
+        for (int x = 0; x < 8; ++x) n += st[16 * x];
+        *surviving = n;
+    }
+    return GME_OK;
 }
 
 extern "C" void* gme_stream(gme_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -508,6 +539,119 @@ extern "C" int gme_seq_bbme(gme_seq* s, int fd, int bs, int sw, int procedure, i
         job.sqbox_stride = p.stride;
     }
     return launch_bbme(s->ctx, job);
+}
+
+// ---------------------------------------------------------------------------
+// host frames -> fields with the upload overlapped (results.py:41-50 hands over host arrays)
+// ---------------------------------------------------------------------------
+extern "C" void* gme_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        gme_set_error("gme_host_alloc: cannot pin %zu bytes", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void gme_host_free(void* p)
+{
+    if (p) hipHostFree(p);
+}
+
+extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_stride, int64_t frame_stride, int count,
+                                     int fd, int bs, int sw, int procedure, int pnorm, int chunk_frames, int32_t* mf_out)
+{
+    GME_REQUIRE(s != nullptr && frames != nullptr && mf_out != nullptr, GME_ERR_ARG, "gme_seq_bbme_streamed: null pointer");
+    gme_ctx* ctx = s->ctx;
+    GME_ENTER(ctx);
+    GME_REQUIRE(count >= 1 && count <= s->N && row_stride >= s->W, GME_ERR_ARG,
+                "gme_seq_bbme_streamed: %d frames into a sequence of %d", count, s->N);
+    GME_REQUIRE(fd >= 1 && fd < count, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
+    GME_REQUIRE(bs >= 1 && chunk_frames >= 1, GME_ERR_ARG, "block_size %d, chunk of %d frames", bs, chunk_frames);
+    int rc = bbme_check_args(s->H, s->W, bs, sw, procedure, pnorm);
+    if (rc) return rc;
+    const int pairs = count - fd, h = s->H / bs, w = s->W / bs;
+    const size_t per = (size_t)h * w * 2;
+    rc = ensure(&s->mv, &s->mv_bytes, (size_t)(s->N - fd) * per * sizeof(int32_t));
+    if (rc) return rc;
+    s->mv_h = h; s->mv_w = w; s->mv_pairs = pairs;
+    const Plane& p = s->level[2];
+    const int aux = bbme_aux_kind(bs, sw, procedure, pnorm);
+    if (aux) {
+        rc = ensure(&s->sqbox[2], &s->sqbox_bytes[2], (size_t)p.stride * p.count * sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    if (!ctx->copy_stream) {
+        GME_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        GME_HIP_TRY(hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
+    }
+    s->pyramids_valid = false;
+    s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
+    gme_drop_run(s);
+    const int nchunks = (count + chunk_frames - 1) / chunk_frames;
+    std::vector<hipEvent_t> up(nchunks, nullptr), done(nchunks, nullptr);
+    auto cleanup = [&]() { for (auto e : up) if (e) hipEventDestroy(e); for (auto e : done) if (e) hipEventDestroy(e); };
+#define STREAM_TRY(expr) do { if ((expr) != hipSuccess) { gme_set_error("%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
+                               hipStreamSynchronize(ctx->copy_stream); hipStreamSynchronize(ctx->back_stream); hipStreamSynchronize(ctx->stream); \
+                               cleanup(); return GME_ERR_HIP; } } while (0)
+    // earlier work of this context may still read or write the planes / the field buffer
+    hipEvent_t gate = nullptr;
+    STREAM_TRY(hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    up.push_back(gate);                                        // destroyed with the others
+    STREAM_TRY(hipEventRecord(gate, ctx->stream));
+    STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream, gate, 0));
+    STREAM_TRY(hipStreamWaitEvent(ctx->back_stream, gate, 0));
+    int p_done = 0;                                            // pairs searched so far
+    for (int c = 0; c < nchunks; ++c) {
+        const int f0 = c * chunk_frames, f1 = f0 + chunk_frames < count ? f0 + chunk_frames : count;
+        STREAM_TRY(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
+        STREAM_TRY(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
+        // upload of chunk c on the copy stream: it runs while the compute stream still searches chunk c - 1
+        if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
+            STREAM_TRY(hipMemcpy2DAsync(p.at(f0), p.pitch, frames + (int64_t)f0 * frame_stride, row_stride, s->W,
+                                        (size_t)s->H * (f1 - f0), hipMemcpyHostToDevice, ctx->copy_stream));
+        } else {
+            for (int i = f0; i < f1; ++i)
+                STREAM_TRY(hipMemcpy2DAsync(p.at(i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
+                                            hipMemcpyHostToDevice, ctx->copy_stream));
+        }
+        STREAM_TRY(hipEventRecord(up[c], ctx->copy_stream));
+        STREAM_TRY(hipStreamWaitEvent(ctx->stream, up[c], 0));
+        const int p1 = f1 - fd;                                // pairs [p_done, p1) have both frames on the device now
+        if (p1 > p_done) {
+            BbmeJob job;
+            job.prev = p.at(p_done); job.cur = p.at(p_done + fd); job.plane_stride = p.stride; job.pairs = p1 - p_done;
+            job.H = s->H; job.W = s->W; job.pitch = p.pitch;
+            job.bs = bs; job.sw = sw; job.procedure = procedure; job.pnorm = pnorm;
+            job.mf = s->mv + per * p_done; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
+            job.chained = p_done > 0;
+            if (aux) {
+                // box sums of squares of the `cur` frames this chunk is the first to use
+                const int t0 = p_done + fd;                    // == the previous chunk's end, or fd for the first pairs
+                rc = launch_aux_table(ctx, aux, p.at(t0), p.stride, f1 - t0, p.H, p.W, p.pitch, s->sqbox[2] + (size_t)t0 * p.stride, p.stride);
+                if (rc == GME_OK) { job.sqbox_cur = s->sqbox[2] + (size_t)(p_done + fd) * p.stride; job.sqbox_stride = p.stride; }
+            }
+            if (rc == GME_OK) rc = launch_bbme(ctx, job);
+            if (rc != GME_OK) {
+                hipStreamSynchronize(ctx->copy_stream); hipStreamSynchronize(ctx->back_stream); hipStreamSynchronize(ctx->stream);
+                cleanup();
+                return rc;
+            }
+            STREAM_TRY(hipEventRecord(done[c], ctx->stream));
+            STREAM_TRY(hipStreamWaitEvent(ctx->back_stream, done[c], 0));
+            STREAM_TRY(hipMemcpyAsync(mf_out + per * p_done, s->mv + per * p_done, per * (p1 - p_done) * sizeof(int32_t),
+                                      hipMemcpyDeviceToHost, ctx->back_stream));
+            p_done = p1;
+        }
+    }
+#undef STREAM_TRY
+    hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->back_stream);
+    rc = ctx_finish(ctx);
+    cleanup();
+    if (aux) { s->sqbox_valid[2] = (count == s->N); s->sqbox_kind[2] = aux; }
+    if (e1 != hipSuccess || e2 != hipSuccess) { gme_set_error("gme_seq_bbme_streamed: copy stream failed"); return GME_ERR_HIP; }
+    return rc;
 }
 
 extern "C" int gme_seq_read_mv(gme_seq* s, int first_pair, int count, int32_t* mf_out)

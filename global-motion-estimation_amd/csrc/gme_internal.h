@@ -51,9 +51,17 @@ struct gme_ctx {
     // growable device scratch for the single-pair convenience calls
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    int* status = nullptr;        // device word set by kernels whose safety guards trip; 1 KiB: words 64.. are the
-                                  // per-XCD tile counters of the persistent search kernels (16 words apart)
+    int* status = nullptr;        // device words (GME_STATUS_WORDS): [0] set by kernels whose safety guards trip;
+                                  // [GME_STATUS_TILECTR ..] per-XCD tile counters of the persistent search kernels,
+                                  // [GME_STATUS_STATS ..] per-XCD statistics of the last block-matching call (16 words apart)
+    void* comm = nullptr;         // RCCL communicator (gme_comm.hip), one per context = per rank
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t copy_stream = nullptr, back_stream = nullptr;   // gme_seq_bbme_streamed: uploads / read-backs beside the kernels
+    char plan[192] = "";          // kernel / tile shape / schedule the last block-matching call chose (gme_last_bbme_info)
+    long long plan_patches = 0;   // candidate patches that call's bound was applied to (0: a kernel without elimination)
 };
+constexpr int GME_STATUS_WORDS = 1024, GME_STATUS_TILECTR = 64, GME_STATUS_STATS = 256;
+void plan_note(gme_ctx* ctx, long long patches, const char* fmt, ...);
 
 int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);
 int plane_alloc(gme_ctx* ctx, Plane* p, int count, int H, int W);
@@ -115,6 +123,7 @@ struct BbmeJob {
     int32_t* mf;                  // [pairs][H/bs][W/bs][2]
     const uint32_t* sqbox_cur;    // optional, matches `cur` planes: [pairs][H][pitch] uint32
     int64_t sqbox_stride;         // elements between consecutive planes
+    bool chained = false;         // a later chunk of one streamed call: keep the plan text and the statistics
 };
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,

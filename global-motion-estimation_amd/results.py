@@ -19,6 +19,7 @@ from sequence import ShardedSequence
 from utils import draw_motion_field, get_video_frames, write_image
 
 FRAME_DISTANCE = 1          # results.py:11
+STREAMS = 3                 # HIP streams (and host threads) the video's pairs are cut into
 
 
 def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progress=False):
@@ -37,7 +38,9 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
     psnr_dict = {}
     if len(frames) <= fd:
         return psnr_dict
-    seq = ShardedSequence(shape[0], shape[1], len(frames), fd)
+    # a few streams per GPU: each lane uploads its range of the video in one copy and then works on it,
+    # so one lane's host->device copy and 3x3 solves run beside the other lanes' kernels
+    seq = ShardedSequence(shape[0], shape[1], len(frames), fd, streams=STREAMS)
     seq.load(frames)
     params = seq.estimate()                                   # motion.global_motion_estimation per pair
     psnr = seq.compensate(params)                             # compensate_frame + PSNR per pair
@@ -49,7 +52,7 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
             print("[%-20s] %d/%d frames" % ("=" * int(20 * j), idx, len(frames)))
         if save_path is not None:
             previous, current = frames[p], frames[idx]
-            compensated = seq.seq.read_compensated(p)
+            compensated = seq.read_compensated(p)
             model_motion_field = motion.get_motion_field_affine(field_shape, parameters=params[p])
             write_image(os.path.join(save_path, "frames", "") + str(idx - 5) + ".png", previous)
             write_image(os.path.join(save_path, "compensated", "") + str(idx - 5) + ".png", compensated)

@@ -46,8 +46,7 @@ def gather_parameters(local, n_pairs, rank, world, device=None):
     import torch
     import torch.distributed as dist
     k = local.shape[1] if local.ndim == 2 else 6
-    sizes = [shard_range(n_pairs, r, world) for r in range(world)]
-    longest = max(b - a for a, b in sizes)
+    longest, sizes = pad_and_trim(n_pairs, world)
     buf = torch.zeros((longest, k), dtype=torch.float64)
     if len(local):
         buf[:len(local)] = torch.from_numpy(local)
@@ -57,6 +56,96 @@ def gather_parameters(local, n_pairs, rank, world, device=None):
     dist.all_gather(out, buf)
     rows = [o.cpu().numpy()[:b - a] for o, (a, b) in zip(out, sizes)]
     return np.concatenate(rows, axis=0)
+
+
+# ---- the library's own RCCL communicator (gme_comm_*, include/gme_hip.h): no torch involved -------------
+def _id_file():
+    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of this node.  All ranks of one
+    launch share their parent (torch.distributed.run's agent, or the test's spawner), so its pid keeps
+    a stale file of an earlier launch on the same port from ever being read."""
+    import os
+    return os.environ.get("GME_COMM_ID_FILE") or "/tmp/gme_rccl_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+
+
+def comm_exchange_id(make_id, rank, world, timeout_s=180.0):
+    """Rank 0 calls make_id() -> bytes and publishes them; every rank returns the same bytes."""
+    import os
+    import time
+    path = _id_file()
+    if rank == 0:
+        blob = make_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)                    # atomic: readers see nothing or everything
+        return blob
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if len(blob) == 128:
+                return blob
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout_s))
+        time.sleep(0.02)
+
+
+def comm_init(ctx, rank, world):
+    """Collective: give `ctx` an RCCL communicator spanning the `world` ranks of this node."""
+    import ctypes
+    import os
+    lib = ctx.lib
+
+    def make_id():
+        buf = ctypes.create_string_buffer(128)
+        _native._check(lib.gme_comm_unique_id(buf), lib)
+        return buf.raw
+    blob = comm_exchange_id(make_id, rank, world) if world > 1 else make_id()
+    _native._check(lib.gme_comm_init(ctx.handle, blob, rank, world), lib)
+    comm_barrier(ctx)
+    if rank == 0 and world > 1:
+        try:
+            os.unlink(_id_file())
+        except OSError:
+            pass
+
+
+def comm_destroy(ctx):
+    _native._check(ctx.lib.gme_comm_destroy(ctx.handle), ctx.lib)
+
+
+def comm_max(ctx, value):
+    import ctypes
+    v = np.array([float(value)], dtype=np.float64)
+    _native._check(ctx.lib.gme_comm_allreduce_max(ctx.handle, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1), ctx.lib)
+    return float(v[0])
+
+
+def comm_barrier(ctx):
+    comm_max(ctx, 0.0)
+
+
+def pad_and_trim(n_pairs, world):
+    """(rows of the largest shard, [(start, stop)] per rank): the fixed block size of the all-gather
+    and how to cut the padding off again."""
+    sizes = [shard_range(n_pairs, r, world) for r in range(world)]
+    return max(1, max(b - a for a, b in sizes)), sizes
+
+
+def gather_parameters_rccl(ctx, local, n_pairs, rank, world):
+    """gather_parameters over the library's RCCL communicator (gme_shard_gather)."""
+    import ctypes
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    k = local.shape[1] if local.ndim == 2 else 6
+    longest, sizes = pad_and_trim(n_pairs, world)
+    out = np.empty((world, longest, k), dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    _native._check(ctx.lib.gme_shard_gather(ctx.handle, local.ctypes.data_as(dp), len(local), k, longest, out.ctypes.data_as(dp)),
+                   ctx.lib)
+    return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
 
 
 class _Lane:
@@ -134,12 +223,19 @@ class ShardedSequence:
             lane.seq.invalidate_pyramids()
 
     def load(self, frames):
-        """`frames` is the WHOLE video (uint8[N, H, W] or a list); only this rank's slice is uploaded."""
-        for lane in self.lanes:
-            for k in range(lane.seq.N):
-                g = self.first_frame + lane.lo + k
-                if g < len(frames):
-                    lane.seq.upload(k, np.ascontiguousarray(frames[g], dtype=np.uint8)[None])
+        """`frames` is the WHOLE video (uint8[N, H, W] or a list); only this rank's slice is uploaded:
+        one copy per lane (its frames back to back), the lanes' copies in their own host threads so that
+        one lane's upload runs beside another lane's kernels."""
+        def run(lane):
+            g0 = self.first_frame + lane.lo
+            n = max(0, min(lane.seq.N, len(frames) - g0))
+            if n == 0:
+                return
+            if isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8:
+                lane.seq.upload(0, frames[g0:g0 + n])
+            else:
+                lane.seq.upload(0, np.stack([np.asarray(f, dtype=np.uint8) for f in frames[g0:g0 + n]]))
+        self._each(run)
 
     def synth(self, seed, t0=0):
         """Generate this rank's slice of the synthetic sequence `seed` (video frame k = time t0 + k) on its own GPU."""

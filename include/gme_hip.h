@@ -16,8 +16,10 @@
  *     are int32[h][w][2] with [..][0] = column (x) and [..][1] = row (y)
  *     displacement, position in `cur` minus position in `prev` (bbme.py:176-177).
  *   - the caller allocates every output; the library owns device memory inside the
- *     opaque gme_ctx / gme_seq objects; one HIP stream per context; a context is not
- *     thread-safe (the reference is single-threaded).
+ *     opaque gme_ctx / gme_seq objects; one HIP stream per context.  Every entry point locks
+ *     its context for the whole call, so threads may share a context (their calls serialise;
+ *     the reference is single-threaded); use one context per thread for
+ *     concurrency.
  *   - integer results (motion vectors, masks, model fields, compensated frames,
  *     squared-error sums) are bit-exact with the reference; the normal-equation
  *     sums are bit-exact float64; the 3x3 solve stays on the host (NumPy) because
@@ -26,6 +28,7 @@
 #ifndef GME_HIP_H
 #define GME_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -64,6 +67,15 @@ GME_API int gme_device_info(gme_ctx *ctx, char *name, int name_len, int *cu_coun
 /* opaque handle of the context's HIP stream (hipStream_t), for callers that
  * want to order their own work or events after the library's */
 GME_API void *gme_stream(gme_ctx *ctx);
+
+/* Diagnostics of the context's last block-matching call (gme_bbme_u8, gme_seq_bbme, or the last
+ * level search of a staged GME run): the kernel / tile shape / schedule the launch plan chose, e.g.
+ * "k_exh_sea16p<3,6> tiles 2x4 persistent-dynamic grid 2048 lds 34864", and for the successive-
+ * elimination kernels how many candidate patches the bound was applied to and how many it left
+ * for exact evaluation (both 0 for kernels that evaluate every candidate, bbme.py:146-174).
+ * No reference counterpart; tests use it to assert which kernel instance they exercised.
+ * Any pointer may be NULL.  Synchronises. */
+GME_API int gme_last_bbme_info(gme_ctx *ctx, char *plan, int plan_len, int64_t *patches, int64_t *surviving);
 
 /* HIP-event stopwatch on the context's stream (bench.py: kernel time of the timed region) */
 GME_API int gme_timer_start(gme_ctx *ctx);
@@ -112,6 +124,19 @@ GME_API int gme_seq_bbme(gme_seq *seq, int frame_distance, int block_size, int s
                  int procedure, int pnorm);
 GME_API int gme_seq_read_mv(gme_seq *seq, int first_pair, int count, int32_t *mf_out);
 
+/* The same search for frames that still live in host memory (results.py:41-50 hands the path a list of
+ * host arrays, utils.py:9-31): frames [0, count) are uploaded in chunks of `chunk_frames` on a copy
+ * stream while the search of the previous chunk runs, and each chunk's fields are read back into
+ * mf_out[count - fd][H/bs][W/bs][2] behind its kernel.  The frames stay resident in `seq` afterwards.
+ * Page-locked `frames` (gme_host_alloc) cross at link speed; pageable memory works but is staged by
+ * the HIP runtime.  Returns when mf_out is complete. */
+GME_API int gme_seq_bbme_streamed(gme_seq *seq, const uint8_t *frames, int row_stride, int64_t frame_stride,
+                          int count, int frame_distance, int block_size, int search_window, int procedure,
+                          int pnorm, int chunk_frames, int32_t *mf_out);
+/* page-locked host memory for frame loaders (hipHostMalloc); NULL on failure */
+GME_API void *gme_host_alloc(size_t bytes);
+GME_API void gme_host_free(void *p);
+
 /* motion.global_motion_estimation (motion.py:109-136), staged so that the host does
  * the 3x3 solves (motion.py:262-264,280-282) between levels:
  *   begin : pyramids (utils.py:34-51) of all frames, diamond BBME at the three levels
@@ -141,6 +166,23 @@ GME_API int gme_seq_gme_read_stage(gme_seq *seq, int level, int pair, int32_t *g
 GME_API int gme_seq_compensate(gme_seq *seq, int frame_distance, int block_size, const double *params,
                        int64_t *sse_out);
 GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
+
+/* ---------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, contiguous pair ranges per rank (results.py:41-50 carries no state
+ * between pairs), and ONE exchange: the all-gather of the per-pair parameter rows over RCCL / xGMI on
+ * the context's stream.  The reference has no distributed code; SURVEY.md §8(e) defines this split.
+ *   gme_comm_unique_id   rank 0 makes the 128-byte RCCL id; the launcher hands it to the other ranks
+ *                        (file / env / socket -- before or after their contexts exist)
+ *   gme_comm_init        collective over all ranks (ncclCommInitRank)
+ *   gme_shard_gather     rows[n_local][k] of every rank -> out[world][n_max][k], blocks zero-padded to
+ *                        n_max rows (n_max = the largest shard, the same on every rank); synchronises
+ *   gme_comm_allreduce_max   element-wise max of v[n] over the ranks, in place (barrier; max-over-ranks time)
+ * ------------------------------------------------------------------------- */
+GME_API int gme_comm_unique_id(char id_out[128]);
+GME_API int gme_comm_init(gme_ctx *ctx, const char id[128], int rank, int world);
+GME_API int gme_comm_destroy(gme_ctx *ctx);
+GME_API int gme_shard_gather(gme_ctx *ctx, const double *rows, int n_local, int k, int n_max, double *out);
+GME_API int gme_comm_allreduce_max(gme_ctx *ctx, double *v, int n);
 
 #ifdef __cplusplus
 }

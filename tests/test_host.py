@@ -205,3 +205,62 @@ def test_frame_loaders_without_cv2(tmp_path):
     img = utils.draw_motion_field(frames[0], mf)
     assert img.shape == (48, 64, 3) and img.dtype == np.uint8
     assert (img[:, :, 2] == 255).any() and utils.write_image(str(tmp_path / "o.png"), img)
+
+
+_RDV = r'''
+import os, sys
+sys.path[:0] = [%(pkg)r]
+import sequence
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+blob = sequence.comm_exchange_id(lambda: bytes(range(128)), rank, world, timeout_s=60)
+assert blob == bytes(range(128)), rank
+sys.stdout.write("rank%%d got the id\n" %% rank)
+'''
+
+
+def test_rccl_id_rendezvous_and_padding(tmp_path):
+    """The launcher side of gme_comm_init: rank 0 publishes the 128-byte RCCL id through a file keyed by
+    MASTER_PORT and the ranks' common parent pid, the other ranks poll for it (started BEFORE rank 0
+    here); and the fixed block size / trimming of the padded all-gather (gme_shard_gather)."""
+    import sequence
+    script = tmp_path / "rdv.py"
+    script.write_text(_RDV % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
+    env = dict(os.environ, MASTER_PORT="29777")
+    env.pop("GME_COMM_ID_FILE", None)
+    late = [subprocess.Popen([sys.executable, str(script), str(r), "3"], env=env, stdout=subprocess.PIPE, text=True) for r in (1, 2)]
+    import time
+    time.sleep(0.5)
+    first = subprocess.run([sys.executable, str(script), "0", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert first.returncode == 0 and "rank0 got the id" in first.stdout, first.stdout + first.stderr
+    for r, p in zip((1, 2), late):
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0 and ("rank%d got the id" % r) in out
+    path = "/tmp/gme_rccl_29777_%d.id" % os.getpid()
+    assert os.path.exists(path)
+    os.unlink(path)
+    assert sequence.pad_and_trim(7, 2) == (4, [(0, 3), (3, 7)])
+    assert sequence.pad_and_trim(1999, 8)[0] == 250
+    assert sequence.pad_and_trim(0, 4) == (1, [(0, 0)] * 4)
+    # trimming the padded blocks back (what gather_parameters_rccl does with gme_shard_gather's output)
+    longest, sizes = sequence.pad_and_trim(7, 2)
+    full = np.arange(42, dtype=np.float64).reshape(7, 6)
+    out = np.zeros((2, longest, 6))
+    for r, (a, b) in enumerate(sizes):
+        out[r, :b - a] = full[a:b]
+    assert np.array_equal(np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)]), full)
+
+
+def test_bench_helpers():
+    """bench.py's sampling (first and last pair always in), content stacks and profile identity."""
+    sys.path.insert(0, REPO)
+    import bench
+    s = bench.sample_pairs(2048, 64)
+    assert s[0] == 0 and s[-1] == 2047 and len(s) == 64 and s == sorted(set(s))
+    assert bench.sample_pairs(3, 64) == [0, 1, 2]
+    f, h, w = bench.host_content("pan240seq", 120, 480, 720)
+    assert f.shape == (120, 240, 320) and (h, w) == (240, 320) and np.array_equal(f[0], f[100]) and np.array_equal(f[51], f[49])
+    f, h, w = bench.host_content("race", 5, 480, 720)
+    assert f.shape == (5, 480, 720) and np.array_equal(f[0], f[2]) and not np.array_equal(f[0], f[1])
+    assert bench.host_content("flat", 2, 32, 48)[0].min() == 128
+    assert len(bench.kernel_source_sha()) == 16
+    assert bench.byte_ops_per_pair(480, 720, 16, 16) == 2891044 * 256          # SURVEY.md §8(a) a3
