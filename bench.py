@@ -484,7 +484,8 @@ def main():
     }
     if info.get("patches"):
         out["elimination"] = {"patches": info["patches"], "surviving": info["surviving"],
-                              "surviving_fraction": info["surviving"] / info["patches"]}
+                              "surviving_fraction": info["surviving"] / info["patches"],
+                              "tiles_redone_by_brute_force": info["redo_tiles"]}
 
     # ---- HBM traffic and issue statistics of the dominant kernel from the committed rocprofv3 PMC passes of
     # this same command (profiles/): valid only for the kernels they were taken from (kernel_source_sha)
@@ -546,6 +547,7 @@ def main():
             ok = all(np.array_equal(s2.read_mv(p, 1)[0], co.bbme(fr[p], fr[p + 1], bs, sw, proc, pnorm)) for p in chk)
             sweep[kind] = {"frame": "%dx%d" % (w2, h2), "pairs": nsw, "pairs_per_s": nsw / (ms * 1e-3), "kernel": inf["plan"].split(" grid")[0],
                            "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
+                           "tiles_redone_by_brute_force": inf["redo_tiles"],
                            "parity_ok_sampled": bool(ok)}
             s2.close()
         out["content_sweep"] = sweep

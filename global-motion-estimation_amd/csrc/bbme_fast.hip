@@ -40,6 +40,7 @@ struct FastDev {
 };
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
 
 // ---- stage the search window (coalesced dword loads; out-of-frame -> 0) ----
 // thread -> one dword column and every `rstep`-th row: no div/mod inside the loop
@@ -65,27 +66,20 @@ __device__ __forceinline__ void stage_window(const FastDev& d, uint32_t* win, co
     }
 }
 
-template <int R>
-__global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
+// The search of one macroblock by one wave; the window of the workgroup's blocks is staged in `win`.
+// ALDS: the anchors of the workgroup's blocks are staged in LDS (`alds`, 64 dwords per wave) and each anchor
+// row is read just before its first use (one broadcast ds_read_b128, R rows live) instead of sitting in 64
+// SGPRs -- the form the redo loop uses, where the compiler cannot keep the scalar loads (see k_exh_redo16).
+template <int R, bool ALDS = false>
+__device__ __forceinline__ void qsad16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0,
+                                             const uint32_t* alds = nullptr)
 {
-    extern __shared__ uint32_t win[];                 // [win_rows][pitch_dw]
     constexpr int NW = R + 3;                          // 64-bit window pairs per lane and row
-    const int b = blockIdx.x;
-    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
-    if (pair >= d.pairs) return;                       // whole workgroup leaves together
-    const int wg = (b >> 3) % d.wg_per_pair;
-    const int brow = wg / d.wg_per_row;
-    const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
     const int r0 = brow * 16;
     const int NC = 2 * d.sw + 16;
-    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-
-    stage_window(d, win, cur, bcol0, r0);
-    __syncthreads();
-
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bcol = bcol0 + wave;
-    if (bcol >= d.nbc) return;                         // ragged last workgroup (after the barrier)
+    if (bcol >= d.nbc) return;                         // ragged last workgroup
     const int c0 = bcol * 16;
     const int lane = threadIdx.x & 63;
     const int prow = lane >> 2, q = lane & 3;
@@ -95,10 +89,12 @@ __global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
                                                (long long)r0 * d.pitch + c0);
     const int apitch = d.pitch >> 2;
     uint32_t A[16][4];
+    if (!ALDS) {
 #pragma unroll
-    for (int a = 0; a < 16; ++a)
+        for (int a = 0; a < 16; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+            for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+    }
 
     // ---- sliding SAD over this lane's R x 4R candidates ----
     uint64_t acc[R][R];
@@ -113,6 +109,11 @@ __global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
         uint64_t w[NW];
 #pragma unroll
         for (int s = 0; s < NW; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
+        if (ALDS && t < 16) {
+            // volatile: keeps the read at this step (hoisted to the top, all 16 rows would be live at once)
+            const u32x4_v v = *(const volatile u32x4_v*)(alds + wave * 64 + t * 4);
+            A[t][0] = v.x; A[t][1] = v.y; A[t][2] = v.z; A[t][3] = v.w;
+        }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int a = t - i;                       // anchor row matched by window row t
@@ -180,6 +181,29 @@ __global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
     }
 }
 
+template <int R>
+__global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
+{
+    extern __shared__ uint32_t win[];                 // [win_rows][pitch_dw]
+    const int b = blockIdx.x;
+    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    if (pair >= d.pairs) return;                       // whole workgroup leaves together
+    const int wg = (b >> 3) % d.wg_per_pair;
+    const int brow = wg / d.wg_per_row;
+    const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    __syncthreads();
+    qsad16_block<R>(d, win, pair, brow, bcol0);
+}
+
+// Redo form (hostile tiles of the elimination kernels, bbme_sea_common.h: SeaDev::redo_list): a fixed grid
+// of workgroups draws items -- one block row of a listed tile each -- from a counter until the list is done.
+struct RedoDev {
+    const uint32_t* list;         // tile number inside its XCD's tiles << 3 | xcd
+    const uint32_t* count;        // tiles listed (written by the kernel launched before this one)
+    uint32_t* head;               // next item
+    int tr, tile_wg_per_row, tile_wg_per_pair;      // the elimination kernel's tile grid (tiles are tr x nb blocks)
+};
 
 // ---------------------------------------------------------------------------
 // Exhaustive MSE, bs = 16:  SSD = sum(A^2) + sum(B^2) - 2 sum(A.B).
@@ -191,23 +215,13 @@ __global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
 //   sum(A^2)  64 v_dot4 + a wave reduction, once per block.
 // All terms are exact integers < 2^26 (bs = 16), equal to the reference's float32 sums (bbme.py:94).
 // ---------------------------------------------------------------------------
-template <int R>
-__global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
+template <int R, bool ALDS = false>
+__device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0,
+                                            const uint32_t* alds = nullptr)
 {
-    extern __shared__ uint32_t win[];
     constexpr int NW = R + 4;                          // window dwords per lane and row
-    const int b = blockIdx.x;
-    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
-    if (pair >= d.pairs) return;
-    const int wg = (b >> 3) % d.wg_per_pair;
-    const int brow = wg / d.wg_per_row;
-    const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
     const int r0 = brow * 16;
     const int NC = 2 * d.sw + 16;
-    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-    stage_window(d, win, cur, bcol0, r0);
-    __syncthreads();
-
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bcol = bcol0 + wave;
     if (bcol >= d.nbc) return;
@@ -219,14 +233,16 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
     const uint32_t* anchor = (const uint32_t*)aptr;
     const int apitch = d.pitch >> 2;
     uint32_t A[16][4];
+    if (!ALDS) {
 #pragma unroll
-    for (int a = 0; a < 16; ++a)
+        for (int a = 0; a < 16; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+            for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+    }
     // sum of squares of the anchor: lane l takes dword l of the block
     uint32_t a2;
     {
-        const uint32_t mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        const uint32_t mine = ALDS ? alds[wave * 64 + lane] : *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
         a2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) a2 += (uint32_t)__shfl_xor((int)a2, m, 64);
@@ -246,6 +262,11 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
         uint32_t w[NW];
 #pragma unroll
         for (int s = 0; s < NW; ++s) w[s] = lrow[t * d.pitch_dw + s];
+        if (ALDS && t < 16) {
+            // volatile: keeps the read at this step (hoisted to the top, all 16 rows would be live at once)
+            const u32x4_v v = *(const volatile u32x4_v*)(alds + wave * 64 + t * 4);
+            A[t][0] = v.x; A[t][1] = v.y; A[t][2] = v.z; A[t][3] = v.w;
+        }
         uint32_t sh[NW - 1][4];                        // sh[s][e] = bytes 4s+e .. 4s+e+3 of the row
 #pragma unroll
         for (int s = 0; s < NW - 1; ++s) {
@@ -317,6 +338,64 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
     }
 }
 
+template <int R>
+__global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
+{
+    extern __shared__ uint32_t win[];
+    const int b = blockIdx.x;
+    const int pair = (b / 8 / d.wg_per_pair) * 8 + (b & 7);
+    if (pair >= d.pairs) return;
+    const int wg = (b >> 3) % d.wg_per_pair;
+    const int brow = wg / d.wg_per_row;
+    const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
+    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    __syncthreads();
+    dot16_block<R>(d, win, pair, brow, bcol0);
+}
+
+// In this loop form the compiler no longer keeps the 64 anchor dwords in SGPRs (the field stores and counter
+// atomics of earlier rounds may alias the frames as far as it can prove, and SGPRs are short anyway): it moved
+// them to VGPRs (86-128 per wave, scratch for MSE).  So the anchors are staged in LDS here and read row by row
+// (ALDS form of the search bodies): 60-80 VGPRs, no scratch.
+template <int R, bool MSE>
+__global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d0, RedoDev r, const uint8_t* __restrict__ prev,
+                                                        const uint8_t* __restrict__ cur, int32_t* __restrict__ mf,
+                                                        const uint32_t* __restrict__ list, uint32_t* __restrict__ head)
+{
+    extern __shared__ uint32_t win[];
+    __shared__ uint32_t item_s;
+    FastDev d = d0;
+    d.prev = prev; d.cur = cur; d.mf = mf;
+    const uint32_t total = *r.count * (uint32_t)r.tr;
+    if (total == 0) return;                                // friendly content: nothing was listed, no atomic is spent
+    for (;;) {
+        if (threadIdx.x == 0) item_s = atomicAdd(head, 1u);
+        __syncthreads();
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_s);
+        if (item >= total) break;
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[item / (uint32_t)r.tr]);
+        const int row_in_tile = (int)(item % (uint32_t)r.tr), xcd = (int)(ent & 7u), t = (int)(ent >> 3);
+        const int lp = t / r.tile_wg_per_pair, wg = t - lp * r.tile_wg_per_pair;
+        const int trow = wg / r.tile_wg_per_row, bcol0 = (wg - trow * r.tile_wg_per_row) * d.nb;
+        const int pair = lp * 8 + xcd, brow = trow * r.tr + row_in_tile;
+        const bool ok = brow < d.nbr && pair < d.pairs;                                     // ragged last tile row
+        uint32_t* alds = win + d.win_rows * d.pitch_dw;                                      // [nb][64] anchors
+        if (ok) {
+            stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+            if (bcol0 + wave < d.nbc)
+                alds[wave * 64 + lane] = *(const uint32_t*)(d.prev + (long long)pair * d.plane_stride +
+                                                            (long long)(brow * 16 + (lane >> 2)) * d.pitch + (bcol0 + wave) * 16 + (lane & 3) * 4);
+        }
+        __syncthreads();
+        if (ok) {
+            if (MSE) dot16_block<R, true>(d, win, pair, brow, bcol0, alds);
+            else qsad16_block<R, true>(d, win, pair, brow, bcol0, alds);
+        }
+        __syncthreads();                                   // the next item restages `win` and redraws item_s
+    }
+}
+
 // 16x16 box sums of squares of one plane stack in ONE pass (5.5 bytes of HBM traffic per pixel
 // instead of the ~15 of a rows pass + a columns pass through a uint32 scratch plane).
 // Thread -> four adjacent columns x .. x+3 (x % 4 == 0) of a chunk of SQ_CHUNK output rows:
@@ -325,7 +404,6 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
 //   S(y)   = S(y-1) + h(y+15) - h(y-1), the last 16 h vectors held in a register ring (the row
 //            loop is unrolled in groups of 16 so that the ring indices are compile-time).
 // Each chunk re-walks 15 warm-up rows (1 byte per pixel, cheap next to the 4-byte outputs).
-typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
 constexpr int SQ_CHUNK = 32;
 
 __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch)
@@ -456,6 +534,45 @@ int launch_bbme_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     }
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
+    return GME_OK;
+}
+
+// Brute-force search of the tiles an elimination kernel listed (launched right behind it on the same stream).
+// nb = the tile's width in blocks; the grid is fixed, workgroups that find the list empty leave at once.
+int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int tile_wg_per_row, int tile_wg_per_pair,
+                    const uint32_t* list, const uint32_t* count, uint32_t* head)
+{
+    const bool mse = job.pnorm == GME_NORM_MSE;
+    FastDev d;
+    d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
+    d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
+    d.nbr = job.H / 16; d.nbc = job.W / 16; d.mf = job.mf;
+    d.sqbox = job.sqbox_cur; d.sqbox_stride = job.sqbox_stride;
+    d.nb = tc;
+    d.wg_per_row = tile_wg_per_row; d.wg_per_pair = tile_wg_per_pair * tr;     // unused by the redo form
+    d.win_rows = 16 * R + 15;
+    const int need_dw = (tc - 1) * 4 + 3 * R + (R + 2) + 2;
+    d.pitch_dw = pick_pitch_dw(need_dw, R);
+    const size_t lds = (size_t)d.win_rows * d.pitch_dw * 4 + (size_t)tc * 256;       // window + one anchor per wave
+    RedoDev r;
+    r.list = list; r.count = count; r.head = head;
+    r.tr = tr; r.tile_wg_per_row = tile_wg_per_row; r.tile_wg_per_pair = tile_wg_per_pair;
+    int per_cu = 32 / tc;                                                   // resident workgroups: 32 wave slots ...
+    const int by_lds = (int)((160 * 1024) / (lds + 1024));                   // ... and LDS
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu < 1) per_cu = 1;
+    const dim3 grid((unsigned)(per_cu * ctx->prop.multiProcessorCount)), block(64 * tc);
+#define REDO_LAUNCH(RR) do { if (mse) hipLaunchKernelGGL((k_exh_redo16<RR, true>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); \
+                             else hipLaunchKernelGGL((k_exh_redo16<RR, false>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); } while (0)
+    switch (R) {
+    case 1: REDO_LAUNCH(1); break;
+    case 2: REDO_LAUNCH(2); break;
+    case 3: REDO_LAUNCH(3); break;
+    case 4: REDO_LAUNCH(4); break;
+    default: REDO_LAUNCH(5); break;
+    }
+#undef REDO_LAUNCH
+    GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }
 

@@ -77,9 +77,10 @@ __device__ __forceinline__ void lower_bounds(const uint64_t* sp0, int XQ, int pr
 
 // Phases A' .. F of one tile.  On entry the window and the anchors are staged, *count == 0 and the
 // workgroup has passed a barrier; there is no barrier after F.
+// Returns true (workgroup-uniform) when the tile was handed to the redo kernel instead (SeaDev::redo_list).
 template <int R, bool E4>
-__device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
-                                            uint32_t mine, uint32_t a01, uint32_t a23, int tid)
+__device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
+                                            uint32_t mine, uint32_t a01, uint32_t a23, int tid, int tile_id)
 {
     const int NB = d.nb, T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
@@ -107,9 +108,6 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
     // ---- B: lower bounds of the wave's own block --------------------------------------------
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
     const bool rows_inside = NC == 16 * R && lo_r == 0 && hi_r == NC - 1;   // and no padding candidates
-    uint32_t patch_lb[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) patch_lb[k] = 0xFFFFFFFFu;
     uint32_t ub_key = 0xFFFFFFFFu;
     if (wave_ok) {
         const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
@@ -121,10 +119,14 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             lower_bounds<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
         else
             lower_bounds<R, true>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
-        uint32_t lb_key = 0xFFFFFFFFu;
+        // pkd[k] = (smallest bound of patch k) << 13 | scan index of the patch's FIRST candidate: no candidate of the
+        // patch can have a smaller key (sad << 13 | scan index).  A patch without valid candidates keeps 0xFFFFE000 | index,
+        // above every real key (sad <= 65280 < 2^16).
+        const uint32_t first_idx = (uint32_t)((q * 4 * R) * NC + prow * R);
+        uint32_t pkd[R], lb_key = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            if (pkey[k] != 0xFFFFFFFFu) patch_lb[k] = pkey[k] >> 13;
+            pkd[k] = (pkey[k] & 0xFFFFE000u) | (first_idx + (uint32_t)(4 * k * NC));
             lb_key = min(lb_key, pkey[k]);
         }
         if (lb_key != 0xFFFFFFFFu) lb_key += (uint32_t)lane << 7;      // local < 4R*R <= 100 < 128
@@ -150,18 +152,27 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             ub_key = min(((packed & 0xFFFFu) << 13) | (uint32_t)idx0, ((packed >> 16) << 13) | (uint32_t)idx1);
         }
         if (lane == 0) best[2 * wave] = ub_key;
-        // ---- D: surviving patches -> workgroup list
-        const uint32_t ub = ub_key >> 13;
+        // ---- D: surviving patches -> workgroup list.  A candidate replaces the best one only with a smaller
+        // key (sad << 13 | scan index: bbme.py:171 keeps the FIRST strict minimum), and its key is at least
+        // LB << 13 | index, so a patch whose smallest possible key -- its bound with the scan index of its first
+        // candidate -- does not undercut ub_key holds no winner.  On flat content (every cost ties) this
+        // leaves nothing behind the first candidate in scan order instead of everything.
 #pragma unroll
         for (int k = 0; k < R; ++k)
-            if (patch_lb[k] <= ub) {
+            if (pkd[k] < ub_key) {
                 const uint32_t slot = atomicAdd(count, 1u);
-                work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];   // LB <= 65280
+                work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | (pkd[k] >> 13);   // LB <= 65280
             }
     }
     STAMP(5);
     __syncthreads();
     STAMP(6);
+#ifndef SEA_NO_REDO
+    if (d.redo_list && (int)*count > d.redo_threshold) {     // workgroup-uniform: hostile tile, brute force is cheaper
+        if (tid == 0) push_redo(d, tile_id, (int)(blockIdx.x & 7));
+        return true;
+    }
+#endif
 
     if constexpr (E4) {
         // ---- E (variant): four lanes per patch ---------------------------------------------------
@@ -173,14 +184,13 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             const int e = base + (tid >> 2);
             bool active = e < n;
             uint32_t ent = 0;
-            if (active) {
-                ent = work[e];
-                active = (ent & 0xFFFFu) <= (best[2 * (ent >> 25)] >> 13);       // dropped by a tightened UB
-            }
-            // the quad is uniform in `active` (same entry), so the DPP exchange below is safe
+            if (active) ent = work[e];
             const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
             const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
             const int prow2 = l2 >> 2, q2 = l2 & 3;
+            // dropped by a tightened UB (same key rule as phase D); the quad is uniform in `active` (same entry),
+            // so the DPP exchange below is safe
+            active = active && (((ent & 0xFFFFu) << 13) | (uint32_t)((q2 * 4 * R + 4 * k2) * NC + prow2 * R)) < best[2 * w2];
             uint64_t acc[R];
     #pragma unroll
             for (int i = 0; i < R; ++i) acc[i] = 0;
@@ -262,11 +272,12 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
             uint32_t ent = 0;
             if (active) {
                 ent = work[e];
-                active = (ent & 0xFFFFu) <= (best[2 * (ent >> 25)] >> 13);       // dropped by a tightened UB
+                const uint32_t first = (uint32_t)(((int)((ent >> 19) & 3) * 4 * R + 4 * (int)((ent >> 16) & 7)) * NC + (int)((ent >> 21) & 15) * R);
+                active = (((ent & 0xFFFFu) << 13) | first) < best[2 * (ent >> 25)];      // dropped by a tightened UB
             }
             if (active) {
                 const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
-            const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
+                const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
                 const int prow2 = l2 >> 2, q2 = l2 & 3;
                 const uint32_t* lrow = win + (16 * wr2 + prow2 * R) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
                 const uint32_t* an = anchor + w2 * ANCHOR_STRIDE;
@@ -333,6 +344,7 @@ __device__ __forceinline__ void tile_phases(const SeaDev& d, uint32_t* lds, cons
         o[0] = ci - d.sw;
         o[1] = ri - d.sw;
     }
+    return false;
 }
 
 // What the shared persistent driver (bbme_sea_common.h: persistent_tiles) needs from this kernel.
@@ -348,10 +360,10 @@ struct MaeTile {
         }
         return p;
     }
-    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
-                                                  uint32_t mine, const Pre& p, int tid)
+    static __device__ __forceinline__ bool phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
+                                                  uint32_t mine, const Pre& p, int tid, int tile_id)
     {
-        tile_phases<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, tid);
+        return tile_phases<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, tid, tile_id);
     }
 };
 
@@ -381,14 +393,15 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    MaeTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
-    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
+    MaeTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
+    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
 }
 
-template <int R, int NV>
+template <int R, int NV, int GEO = 0>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 6)) k_exh_sea16p(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
+    fix_geometry<R, GEO>(d);
     persistent_tiles<NV, MaeTile<R, (R >= 3)>>(d, lds, layout_of(d, R));
 }
 
@@ -414,8 +427,7 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const int nbr = job.H / 16, nbc = job.W / 16;
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
-    d.tile_ctr = nullptr;
-    d.stats = (uint32_t*)ctx->status + GME_STATUS_STATS;
+    d.status = (uint32_t*)ctx->status; d.dynamic = 0;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
@@ -426,6 +438,17 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     GME_REQUIRE(plan(R, nbr, nbc, job.sw, &d, &lds), GME_ERR_ARG, "search window too large for LDS");
     d.sqbox = nullptr; d.sqbox_stride = 0;
     const dim3 block(64 * d.nb);
+    // hostile tiles (bound prunes little) -> brute-force redo kernel behind this one; GME_SEA_REDO=0 switches it off,
+    // GME_SEA_REDO_FRAC sets the share of a tile's patches from which phase E costs more than evaluating everything
+    d.redo_list = nullptr; d.redo_threshold = 0x7FFFFFFF;
+    const bool redo = !(getenv("GME_SEA_REDO") && atoi(getenv("GME_SEA_REDO")) == 0);
+    if (redo) {
+        int rc = ctx_redo_list(ctx, (size_t)job.pairs * d.wg_per_pair, &d.redo_list);
+        if (rc) return rc;
+        const double frac = getenv("GME_SEA_REDO_FRAC") ? atof(getenv("GME_SEA_REDO_FRAC")) : REDO_DEFAULT_FRAC;
+        d.redo_threshold = (int)(frac * d.nb * 64 * R);
+        GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
+    }
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
     // R = 2, 3 with more than 8 staging rows per thread would spill the prefetched tile (64 VGPRs at
@@ -433,13 +456,22 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const bool fits = R <= 1 || R >= 4 || nv <= 8;
     if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
-        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p<%d,%d> tiles %dx%d persistent-%s grid %u lds %zu",
-                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", grid.x, lds);
-        d.tile_ctr = nullptr;
         if (pp.dynamic) {
-            d.tile_ctr = (uint32_t*)ctx->status + GME_STATUS_TILECTR;
-            GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+            d.dynamic = 1;
+            GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
+        // the two BASELINE shapes (720x480 sw 16: 2x4 tiles; 1080p sw 32: 2x6 tiles) have instances with the tile
+        // geometry folded in at compile time; GME_SEA_GENERIC=1 keeps the run-time form (A/B, tests)
+        const bool fixed_ok = !getenv("GME_SEA_GENERIC");
+        const bool fix3 = fixed_ok && R == 3 && nv <= 6 && geometry_matches(d, 3, 2 * 16 + 4);
+        const bool fix5 = fixed_ok && R == 5 && nv <= 8 && geometry_matches(d, 5, 2 * 16 + 6);
+        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p<%d,%d> tiles %dx%d persistent-%s%s grid %u lds %zu",
+                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", (fix3 || fix5) ? " geometry-fixed" : "", grid.x, lds);
+        if (fix3) {
+            hipLaunchKernelGGL((k_exh_sea16p<3, 6, 2 * 16 + 4>), grid, block, lds, ctx->stream, d);
+        } else if (fix5) {
+            hipLaunchKernelGGL((k_exh_sea16p<5, 8, 2 * 16 + 6>), grid, block, lds, ctx->stream, d);
+        } else
 #define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p<RR, NVV>), grid, block, lds, ctx->stream, d)
 #define SEA_LAUNCH_PN(RR) do { if (nv <= 6) SEA_LAUNCH_P(RR, 6); else if (nv <= 8) SEA_LAUNCH_P(RR, 8); \
                                else if (nv <= 12) SEA_LAUNCH_P(RR, 12); else SEA_LAUNCH_P(RR, 16); } while (0)
@@ -473,5 +505,6 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     }
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
+    if (redo) return launch_exh_redo(ctx, job, R, d.tr, d.tc, d.wg_per_row, d.wg_per_pair, d.redo_list, d.status + GME_STATUS_REDO, d.status + GME_STATUS_REDO + 1);
     return GME_OK;
 }

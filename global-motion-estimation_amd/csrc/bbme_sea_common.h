@@ -30,8 +30,18 @@ struct SeaDev {
     uint32_t magic_xq;            // same for n / xq
     unsigned long long magic_wpp; // persistent kernel: n / wg_per_pair == (n * magic_wpp) >> 40 for n < 2^21
     unsigned long long magic_wpr; // same for n / wg_per_row
-    uint32_t* tile_ctr;           // persistent kernel, dynamic schedule: one counter per XCD, 16 words apart (or null)
-    uint32_t* stats;              // per XCD, 16 words apart: [0] patches the bound left for exact evaluation (phase D's list)
+    uint32_t* status;             // the context's status words (gme_internal.h: GME_STATUS_*):
+                                  //   + GME_STATUS_TILECTR  persistent kernel, dynamic schedule: one tile counter per XCD, 16 words apart
+                                  //   + GME_STATUS_STATS    per XCD, 16 words apart: [0] patches the bound left for exact evaluation
+                                  //                         (phase D's list), [1] tiles handed to the brute-force redo kernel
+                                  //   + GME_STATUS_REDO     [0] length of redo_list
+    int dynamic;                  // persistent kernel: draw tiles from the per-XCD counters (else a static stride)
+    // Hostile content (nothing correlates: a scene cut, noise): the bound prunes little and phase E's one-patch-
+    // per-lane evaluation costs more than evaluating everything in the regular layout of k_exh_qsad16 / k_exh_dot16.
+    // A tile whose list is longer than redo_threshold skips phases E and F and goes to redo_list instead
+    // (entry = tile number inside its XCD's tiles << 3 | xcd); the redo kernel launched behind this one searches it.
+    uint32_t* redo_list;          // or null: no fallback
+    int redo_threshold;
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
     const uint32_t* sqbox;        // MSE only: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
@@ -69,7 +79,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 
 // n / dv for n < 4096 and dv < 256 without the 20-odd instructions of an emulated division:
 // magic = 2^20 / dv + 1 overshoots the reciprocal by < 2^-20, so the product is off by < 2^-8 < 1 / dv.
-inline uint32_t div_magic(int dv) { return (1u << 20) / (uint32_t)dv + 1u; }
+constexpr uint32_t div_magic(int dv) { return (1u << 20) / (uint32_t)dv + 1u; }
 // same idea for n < 2^21, dv < 2^18: (n * magic40) >> 40, error < 2^21 / 2^40 < 1 / dv
 inline unsigned long long div_magic40(int dv) { return (1ull << 40) / (unsigned long long)dv + 1ull; }
 __device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(__umul24((uint32_t)n, magic) >> 20); }
@@ -102,13 +112,14 @@ struct Layout {
     int win, anchor, best, count, a2, s8, work, total;
 };
 
-__host__ __device__ inline Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq, int s8_rows)
+__host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq, int s8_rows)
 {
-    Layout l;
+    Layout l{};
     l.win = 0;
     l.anchor = (win_rows * pitch_dw + 3) & ~3;         // 16-byte aligned: anchor rows are read as b128
     l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
-    l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [2] list lengths of earlier tiles
+    l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [2] list lengths of earlier tiles,
+                                                       // [3] streak of hostile tiles (persistent_tiles)
     l.a2 = l.count + 4;
     l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [s8_rows][xq] u16x4
     l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
@@ -228,11 +239,11 @@ __device__ __forceinline__ void anchor_quadrants(uint32_t mine, uint32_t* a01, u
     *a23 = q2 | (q3 << 16);
 }
 
-inline int pick_pitch(int need, int R)
+constexpr int pick_pitch(int need, int R)
 {
     int best_p = need, best_c = 1 << 30;
     for (int p = need; p < need + 33; ++p) {
-        int conflicts = 0, seen[32];
+        int conflicts = 0, seen[32] = {};
         for (int i = 0; i < 32; ++i) seen[i] = 0;
         for (int prow = 0; prow < 8; ++prow)
             for (int q = 0; q < 4; ++q) conflicts += seen[((prow * R) * p + q * R) & 31]++;
@@ -247,18 +258,51 @@ inline int pick_pitch(int need, int R)
 // number of waves a CU keeps resident (160 KiB LDS, 32 waves), discounted by the idle waves of
 // ragged last tiles and by SIMD imbalance, with a bonus for the sharing.  GME_SEA_TILE = "TRxTC"
 // overrides it (A/B runs).  Returns false if nothing fits.
+// LDS geometry of a tile shape: depends on (R, tr, tc) only, so a kernel instantiated for one shape
+// (fix_geometry below) gets every stride, row count and division constant at compile time.
+struct Shape { int tr, tc, pitch, xq; size_t bytes; };
+constexpr Shape shape_of(int R, int tr, int tc)
+{
+    Shape s{};
+    s.tr = tr; s.tc = tc;
+    s.xq = (4 * R + 4 * (tc - 1) + 2) | 1;                          // S8 quads per row, odd pitch
+    const int need_dw = (tc - 1) * 4 + 3 * R + (R - 1) + 5;         // base + k + 4 pairs of two dwords
+    s.pitch = pick_pitch(need_dw > s.xq + 2 ? need_dw : s.xq + 2, R);
+    s.bytes = (size_t)make_layout(R, tr * tc, 16 * R + 15 + 16 * (tr - 1), s.pitch, s.xq, 16 * R + 8 + 16 * (tr - 1)).total * 4;
+    return s;
+}
+
+// Kernels instantiated for one tile shape (GEO = tr * 16 + tc, 0 = any shape at run time) overwrite the
+// geometry fields of their by-value launch descriptor with constants: the compiler then folds every use
+// (strides become immediates, the multiply-shift divisions constants, ~15 SGPRs are never loaded).
+// The host launches such an instance only when plan() chose exactly that shape (geometry_matches).
+template <int R, int GEO>
+__device__ __forceinline__ void fix_geometry(SeaDev& d)
+{
+    if constexpr (GEO != 0) {
+        constexpr int TR = GEO / 16, TC = GEO % 16;
+        constexpr Shape s = shape_of(R, TR, TC);
+        d.tr = TR; d.tc = TC; d.nb = TR * TC;
+        d.magic_tc = div_magic(TC);
+        d.win_rows = 16 * R + 15 + 16 * (TR - 1);
+        d.s8_rows = 16 * R + 8 + 16 * (TR - 1);
+        d.pitch_dw = s.pitch; d.xq = s.xq;
+        d.rstep = 64 * TR * TC / s.pitch;
+        d.magic_pitch = div_magic(s.pitch);
+        d.magic_xq = div_magic(s.xq);
+    }
+}
+
+inline bool geometry_matches(const SeaDev& d, int R, int geo)
+{
+    if (geo == 0) return true;
+    const Shape s = shape_of(R, geo / 16, geo % 16);
+    return d.tr == geo / 16 && d.tc == geo % 16 && d.pitch_dw == s.pitch && d.xq == s.xq;
+}
+
 inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
 {
-    struct Shape { int tr, tc, pitch, xq; size_t bytes; };
-    auto shape = [&](int tr, int tc) {
-        Shape s;
-        s.tr = tr; s.tc = tc;
-        s.xq = (4 * R + 4 * (tc - 1) + 2) | 1;                          // S8 quads per row, odd pitch
-        const int need_dw = (tc - 1) * 4 + 3 * R + (R - 1) + 5;         // base + k + 4 pairs of two dwords
-        s.pitch = pick_pitch(need_dw > s.xq + 2 ? need_dw : s.xq + 2, R);
-        s.bytes = (size_t)make_layout(R, tr * tc, 16 * R + 15 + 16 * (tr - 1), s.pitch, s.xq, 16 * R + 8 + 16 * (tr - 1)).total * 4;
-        return s;
-    };
+    auto shape = [&](int tr, int tc) { return shape_of(R, tr, tc); };
     Shape best = shape(1, 1);
     double best_score = -1.0;
     int force_tr = 0, force_tc = 0;
@@ -315,13 +359,29 @@ inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
     return d->rstep >= 1;
 }
 
+constexpr int REDO_BURST = 15;
+constexpr double REDO_DEFAULT_FRAC = 0.75;     // break-even measured on noise content
+
+__device__ __forceinline__ void push_redo(const SeaDev& d, int tile_in_xcd, int xcd)
+{
+    const uint32_t slot = atomicAdd(d.status + GME_STATUS_REDO, 1u);
+    d.redo_list[slot] = ((uint32_t)tile_in_xcd << 3) | (uint32_t)xcd;
+    atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd + 1, 1u);
+}
+
+// tile number (inside its XCD's tiles) of the one-tile kernels' workgroup: what persistent_tiles calls `t`
+__device__ __forceinline__ int tile_number(const SeaDev& d, int pair, int trow, int bcol0)
+{
+    return (pair >> 3) * d.wg_per_pair + trow * d.wg_per_row + div_small(bcol0, d.magic_tc);
+}
+
 // Persistent form of a search kernel: G workgroups (as many as fit on the chip at once) walk the
 // tiles of "their" XCD's pairs.  The window and anchor of the next tile are fetched into registers
 // while the current one is searched, so the HBM/L2 latency of phase A overlaps phases A' .. F
 // instead of idling the workgroup's waves.  Kern supplies prep() (anchor -> LDS, per-wave anchor
 // statistics) and phases() (A' .. F).
 //
-// Schedule: static (tile += G/8) or, with d.tile_ctr, dynamic: after its first tile a workgroup
+// Schedule: static (tile += G/8) or, with d.dynamic, dynamic: after its first tile a workgroup
 // draws tile numbers G/8 + n from its XCD's counter.  Thread 0 asks one tile ahead, so the
 // atomic's round trip is waited for together with the prefetched window (same vmcnt).  It is an
 // atomicInc, not atomicAdd: LLVM would aggregate an add over the wave and wait for its result at once.
@@ -369,10 +429,10 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         }
     };
     fetch(tile);
-    uint32_t* ctr = d.tile_ctr ? d.tile_ctr + 16 * xcd : nullptr;
+    uint32_t* ctr = d.dynamic ? d.status + GME_STATUS_TILECTR + 16 * xcd : nullptr;
     uint32_t drawn = 0;
     if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
-    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 2] = 0; }
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 2] = 0; lds[L.count + 3] = 0; }
     for (;;) {
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -387,7 +447,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
                     if (row0 + u * d.rstep < d.win_rows) dst[u * dstep] = wv[u];
             }
         }
-        const int pair_c = pair, trow_c = trow, bcol0_c = bcol0;
+        const int pair_c = pair, trow_c = trow, bcol0_c = bcol0, tile_c = tile;
         const uint32_t mine = an_next;
         const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, wave_block(d, trow_c, bcol0_c, wave).ok, mine);
         if (tid == 0) {
@@ -402,12 +462,36 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
             fetch(tile);
             if (ctr && tid == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
         }
-        Kern::phases(d, lds, L, pair_c, trow_c, bcol0_c, mine, pre, tid);
+#ifdef SEA_NO_REDO
+        Kern::phases(d, lds, L, pair_c, trow_c, bcol0_c, mine, pre, tid, tile_c);
+#else
+        // A hostile tile is handed to the redo kernel.  When the tile this workgroup processed just before was
+        // hostile too (a scene cut, a noisy shot: not an isolated occlusion), thread 0's wave also draws the next
+        // tile numbers of this XCD -- consecutive tiles of the same pairs -- and lists them unseen: 3 of them, then
+        // 7, then REDO_BURST while the streak lasts.  Where every tile is hostile only one in REDO_BURST + 1 pays
+        // for the bound phases before brute force does the work anyway; friendly content never takes the branch.
+        if (!Kern::phases(d, lds, L, pair_c, trow_c, bcol0_c, mine, pre, tid, tile_c)) {
+            if (tid == 0) lds[L.count + 3] = 0;            // streak of hostile tiles (thread 0's word)
+        } else if (ctr && wave == 0) {
+            const int streak = (int)lds[L.count + 3];      // same address for the whole wave; only thread 0 writes it
+            const int burst = streak == 0 ? 0 : streak == 1 ? 3 : streak == 2 ? 7 : REDO_BURST;
+            if (burst) {
+                // lane 0 lists the tile it had drawn already, lanes 1 .. burst draw one each (one wave-aggregated
+                // atomic); the last of those becomes thread 0's new `drawn`, the others are listed
+                uint32_t got = 0;
+                if (lane >= 1 && lane <= burst) got = atomicAdd(ctr, 1u);
+                const int t = gx + (int)(lane == 0 ? drawn : got);
+                if (lane < burst && t < ntiles) push_redo(d, t, xcd);
+                drawn = (uint32_t)__shfl((int)got, burst, 64);
+            }
+            if (lane == 0) lds[L.count + 3] = (uint32_t)(streak + 1);
+        }
+#endif
         if (!more) break;
         __syncthreads();                                   // everyone is done with this tile's LDS
     }
     // thread 0 has passed the barrier behind phase D: the last tile's list length is final
-    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * xcd, lds[L.count + 2] + lds[L.count]);
+    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd, lds[L.count + 2] + lds[L.count]);
 }
 
 // Host side of the persistent form: resident workgroups per XCD (what LDS and the 32 wave slots of

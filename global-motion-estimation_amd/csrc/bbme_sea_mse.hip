@@ -64,8 +64,8 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
 
 // Phases A' .. F of one tile (entry conditions as tile_phases() of bbme_sea.hip, plus a2s[] filled).
 template <int R, bool E4>
-__device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
-                                                uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid)
+__device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
+                                                uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid, int tile_id)
 {
     const int T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
@@ -130,14 +130,23 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         if (lane == 0) best[wave] = ub_key;
         // ---- D
         const uint32_t ub16 = (uint32_t)(ub_key >> 21);                // (ssd >> 8) = floor(64 * ssd / 2^14)
+        // UB == 0 (an exact match is known): only another exact match earlier in scan order can replace it
+        // (bbme.py:171 keeps the first minimum), so a patch needs a zero bound AND a first candidate in front
+        // of the best one.  Flat or static content then leaves (almost) nothing instead of everything.
+        const bool exact = (ub_key >> 13) == 0;
+        const uint32_t ub_idx = (uint32_t)ub_key & 0x1FFFu, first_idx = (uint32_t)((q * 4 * R) * NC + prow * R);
 #pragma unroll
         for (int k = 0; k < R; ++k)
-            if (patch_lb[k] <= ub16) {
+            if (patch_lb[k] <= ub16 && (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
                 const uint32_t slot = atomicAdd(count, 1u);
                 work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];
             }
     }
     __syncthreads();
+    if (d.redo_list && (int)*count > d.redo_threshold) {     // workgroup-uniform: hostile tile, brute force is cheaper
+        if (tid == 0) push_redo(d, tile_id, (int)(blockIdx.x & 7));
+        return true;
+    }
 
     // ---- E: LPP lanes per listed patch; lane `sub` takes anchor rows AR*sub .. AR*sub+AR-1 (R+AR-1 window
     // rows), the partial dot products are added inside the quad with DPP moves.  Four lanes per patch
@@ -261,6 +270,7 @@ __device__ __forceinline__ void tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         o[0] = ci - d.sw;
         o[1] = ri - d.sw;
     }
+    return false;
 }
 
 template <int R, bool E4>
@@ -278,10 +288,10 @@ struct MseTile {
         }
         return p;
     }
-    static __device__ __forceinline__ void phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
-                                                  uint32_t mine, const Pre& p, int tid)
+    static __device__ __forceinline__ bool phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
+                                                  uint32_t mine, const Pre& p, int tid, int tile_id)
     {
-        tile_phases_mse<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, p.mine2, tid);
+        return tile_phases_mse<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, p.mine2, tid, tile_id);
     }
 };
 
@@ -305,14 +315,15 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     const typename MseTile<R, E4>::Pre pre = MseTile<R, E4>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (threadIdx.x == 0) lds[L.count] = 0;
     __syncthreads();
-    MseTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x);
-    if (threadIdx.x == 0) atomicAdd(d.stats + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
+    MseTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
+    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
 }
 
-template <int R, int NV>
+template <int R, int NV, int GEO = 0>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 6)) k_exh_sea16p_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
+    fix_geometry<R, GEO>(d);
     persistent_tiles<NV, MseTile<R, false>>(d, lds, layout_of(d, R));
 }
 
@@ -329,8 +340,7 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const int nbr = job.H / 16, nbc = job.W / 16;
     if (nbr == 0 || nbc == 0) return GME_OK;
     SeaDev d;
-    d.tile_ctr = nullptr;
-    d.stats = (uint32_t*)ctx->status + GME_STATUS_STATS;
+    d.status = (uint32_t*)ctx->status; d.dynamic = 0;
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride;
     d.pairs = job.pairs; d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf;
@@ -341,6 +351,17 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     size_t lds = 0;
     if (!plan(R, nbr, nbc, job.sw, &d, &lds)) return GME_OK;        // does not fit: the dot4 kernel takes it
     const dim3 block(64 * d.nb);
+    // hostile tiles (bound prunes little) -> brute-force redo kernel behind this one; GME_SEA_REDO=0 switches it off,
+    // GME_SEA_REDO_FRAC sets the share of a tile's patches from which phase E costs more than evaluating everything
+    d.redo_list = nullptr; d.redo_threshold = 0x7FFFFFFF;
+    const bool redo = !(getenv("GME_SEA_REDO") && atoi(getenv("GME_SEA_REDO")) == 0);
+    if (redo) {
+        int rc = ctx_redo_list(ctx, (size_t)job.pairs * d.wg_per_pair, &d.redo_list);
+        if (rc) return rc;
+        const double frac = getenv("GME_SEA_REDO_FRAC") ? atof(getenv("GME_SEA_REDO_FRAC")) : REDO_DEFAULT_FRAC;
+        d.redo_threshold = (int)(frac * d.nb * 64 * R);
+        GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
+    }
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
     // The persistent form must hold the prefetched tile in registers next to phase E's 4R accumulators
@@ -349,12 +370,22 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     const bool fits = R != 3 || nv <= 12;
     if (pp.use && fits) {
         const dim3 grid((unsigned)(8 * pp.g));
-        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p_mse<%d,%d> tiles %dx%d persistent-%s grid %u lds %zu",
-                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", grid.x, lds);
         if (pp.dynamic) {
-            d.tile_ctr = (uint32_t*)ctx->status + GME_STATUS_TILECTR;
-            GME_HIP_TRY(hipMemsetAsync(d.tile_ctr, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+            d.dynamic = 1;
+            GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
+        // the two BASELINE shapes (720x480 sw 16: 2x4 tiles; 1080p sw 32: 2x6 tiles) have instances with the tile
+        // geometry folded in at compile time; GME_SEA_GENERIC=1 keeps the run-time form (A/B, tests)
+        const bool fixed_ok = !getenv("GME_SEA_GENERIC");
+        const bool fix3 = fixed_ok && R == 3 && nv <= 6 && geometry_matches(d, 3, 2 * 16 + 4);
+        const bool fix5 = fixed_ok && R == 5 && nv <= 8 && geometry_matches(d, 5, 2 * 16 + 6);
+        plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p_mse<%d,%d> tiles %dx%d persistent-%s%s grid %u lds %zu",
+                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", (fix3 || fix5) ? " geometry-fixed" : "", grid.x, lds);
+        if (fix3) {
+            hipLaunchKernelGGL((k_exh_sea16p_mse<3, 6, 2 * 16 + 4>), grid, block, lds, ctx->stream, d);
+        } else if (fix5) {
+            hipLaunchKernelGGL((k_exh_sea16p_mse<5, 8, 2 * 16 + 6>), grid, block, lds, ctx->stream, d);
+        } else
 #define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p_mse<RR, NVV>), grid, block, lds, ctx->stream, d)
 #define SEA_LAUNCH_PN(RR) do { if (nv <= 6) SEA_LAUNCH_P(RR, 6); else if (nv <= 8) SEA_LAUNCH_P(RR, 8); \
                                else if (nv <= 12) SEA_LAUNCH_P(RR, 12); else SEA_LAUNCH_P(RR, 16); } while (0)
@@ -386,5 +417,6 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     }
     GME_HIP_TRY(hipGetLastError());
     *handled = true;
+    if (redo) return launch_exh_redo(ctx, job, R, d.tr, d.tc, d.wg_per_row, d.wg_per_pair, d.redo_list, d.status + GME_STATUS_REDO, d.status + GME_STATUS_REDO + 1);
     return GME_OK;
 }

@@ -88,6 +88,7 @@ extern "C" void gme_destroy(gme_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->redo_list) hipFree(ctx->redo_list);
     if (ctx->status) hipFree(ctx->status);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->back_stream) hipStreamDestroy(ctx->back_stream);
@@ -127,18 +128,20 @@ extern "C" int gme_sync(gme_ctx* ctx)
     return ctx_finish(ctx);
 }
 
-extern "C" int gme_last_bbme_info(gme_ctx* ctx, char* plan, int plan_len, int64_t* patches, int64_t* surviving)
+extern "C" int gme_last_bbme_info(gme_ctx* ctx, char* plan, int plan_len, int64_t* patches, int64_t* surviving,
+                                  int64_t* redo_tiles)
 {
     GME_ENTER(ctx);
     if (plan && plan_len > 0) snprintf(plan, plan_len, "%s", ctx->plan);
     if (patches) *patches = ctx->plan_patches;
-    if (surviving) {
+    if (surviving || redo_tiles) {
         uint32_t st[8 * 16];
         GME_HIP_TRY(hipMemcpyAsync(st, ctx->status + GME_STATUS_STATS, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        int64_t n = 0;
-        for (int x = 0; x < 8; ++x) n += st[16 * x];
-        *surviving = n;
+        int64_t n = 0, r = 0;
+        for (int x = 0; x < 8; ++x) { n += st[16 * x]; r += st[16 * x + 1]; }
+        if (surviving) *surviving = n;
+        if (redo_tiles) *redo_tiles = r;
     }
     return GME_OK;
 }
@@ -187,6 +190,24 @@ int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out)
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
+    return GME_OK;
+}
+
+int ctx_redo_list(gme_ctx* ctx, size_t entries, uint32_t** out)
+{
+    if (entries > ctx->redo_cap) {
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->redo_list) hipFree(ctx->redo_list);
+        ctx->redo_list = nullptr;
+        ctx->redo_cap = 0;
+        const size_t want = (entries + 4095) & ~(size_t)4095;
+        if (hipMalloc((void**)&ctx->redo_list, want * sizeof(uint32_t)) != hipSuccess) {
+            gme_set_error("out of device memory (%zu redo entries)", want);
+            return GME_ERR_NOMEM;
+        }
+        ctx->redo_cap = want;
+    }
+    *out = ctx->redo_list;
     return GME_OK;
 }
 

@@ -57,10 +57,15 @@ struct gme_ctx {
     void* comm = nullptr;         // RCCL communicator (gme_comm.hip), one per context = per rank
     int comm_rank = 0, comm_world = 0;
     hipStream_t copy_stream = nullptr, back_stream = nullptr;   // gme_seq_bbme_streamed: uploads / read-backs beside the kernels
+    uint32_t* redo_list = nullptr;   // tiles the elimination kernels hand to the brute-force redo kernel (grown on demand)
+    size_t redo_cap = 0;             // entries
     char plan[192] = "";          // kernel / tile shape / schedule the last block-matching call chose (gme_last_bbme_info)
     long long plan_patches = 0;   // candidate patches that call's bound was applied to (0: a kernel without elimination)
 };
 constexpr int GME_STATUS_WORDS = 1024, GME_STATUS_TILECTR = 64, GME_STATUS_STATS = 256;
+constexpr int GME_STATUS_REDO = 512;           // [0] tiles listed for the redo kernel, [1] items it has drawn
+int ctx_redo_list(gme_ctx* ctx, size_t entries, uint32_t** out);
+
 void plan_note(gme_ctx* ctx, long long patches, const char* fmt, ...);
 
 int ctx_scratch(gme_ctx* ctx, size_t bytes, void** out);
@@ -126,6 +131,8 @@ struct BbmeJob {
     bool chained = false;         // a later chunk of one streamed call: keep the plan text and the statistics
 };
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
+int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int tile_wg_per_row, int tile_wg_per_pair,
+                    const uint32_t* list, const uint32_t* count, uint32_t* head);
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
                    uint32_t* tmp, uint32_t* out, long long stride);
 // per-frame auxiliary table a fast exhaustive kernel wants for `cur` (BbmeJob::sqbox_cur):

@@ -72,10 +72,12 @@ GME_API void *gme_stream(gme_ctx *ctx);
  * level search of a staged GME run): the kernel / tile shape / schedule the launch plan chose, e.g.
  * "k_exh_sea16p<3,6> tiles 2x4 persistent-dynamic grid 2048 lds 34864", and for the successive-
  * elimination kernels how many candidate patches the bound was applied to and how many it left
- * for exact evaluation (both 0 for kernels that evaluate every candidate, bbme.py:146-174).
+ * for exact evaluation (both 0 for kernels that evaluate every candidate, bbme.py:146-174), and how many
+ * tiles it handed to the brute-force redo kernel because the bound pruned too little there.
  * No reference counterpart; tests use it to assert which kernel instance they exercised.
  * Any pointer may be NULL.  Synchronises. */
-GME_API int gme_last_bbme_info(gme_ctx *ctx, char *plan, int plan_len, int64_t *patches, int64_t *surviving);
+GME_API int gme_last_bbme_info(gme_ctx *ctx, char *plan, int plan_len, int64_t *patches, int64_t *surviving,
+                       int64_t *redo_tiles);
 
 /* HIP-event stopwatch on the context's stream (bench.py: kernel time of the timed region) */
 GME_API int gme_timer_start(gme_ctx *ctx);

@@ -30,6 +30,11 @@ def _contents(kind, n, H, W, rng):
         return rng.integers(0, 256, (n, H, W), dtype=np.uint8)
     if kind == "flat":             # every cost ties at 0: the first candidate in scan order must win
         return np.full((n, H, W), 93, np.uint8)
+    if kind == "mixed":            # left half uncorrelated noise, right half a clean pan: hostile and friendly tiles side by side
+        import synth
+        f = synth.sequence(1234, 0, n, H, W).copy()
+        f[:, :, :W // 2] = rng.integers(0, 256, (n, H, W // 2), dtype=np.uint8)
+        return f
     if kind == "steps":            # few grey levels: many exact ties between real candidates
         base = (rng.integers(0, 3, (H + 64, W + 64)) * 90).astype(np.uint8)
         return np.stack([base[16 + 2 * (t % 5):16 + 2 * (t % 5) + H, 24 - 3 * (t % 4):24 - 3 * (t % 4) + W] for t in range(n)])
@@ -57,23 +62,58 @@ def test_benched_instance_720_every_pair(native, pnorm):
     seq.close()
 
 
-@pytest.mark.parametrize("kind", ["noise", "flat", "steps"])
-def test_benched_instance_720_hostile_content(native, kind):
-    """The same kernel instance on content where the bound prunes little (noise), nothing (flat: all
-    ties) or leaves many exact ties (steps), both norms, every pair against the C oracle."""
+@pytest.mark.parametrize("kind", ["noise", "flat", "steps", "mixed"])
+def test_benched_instance_720_hostile_content(native, kind, monkeypatch):
+    """The same kernel instance on content where the bound prunes little (noise: those tiles go to the
+    brute-force redo kernel), where every cost ties (flat: the key rule prunes everything behind the
+    first candidate), with many exact ties (steps) and with hostile and friendly tiles side by side
+    (mixed), both norms, every pair against the C oracle -- with and without the redo path."""
     ctx = native.default_context()
     co = c_oracle()
     rng = np.random.default_rng(7 + len(kind))
     frames = _contents(kind, 22, 480, 720, rng)
     seq = native.Sequence.from_frames(ctx, frames)
-    for pnorm in (0, 1):
-        seq.bbme(1, 16, 16, 0, pnorm)
-        info = ctx.last_bbme_info()
-        assert info["plan"].startswith("k_exh_sea16p"), info
-        mv = seq.read_mv()
-        for p in range(21):
-            assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, 16, 0, pnorm)), (kind, pnorm, p)
+    want = {pn: [co.bbme(frames[p], frames[p + 1], 16, 16, 0, pn) for p in range(21)] for pn in (0, 1)}
+    for redo in ("1", "0"):
+        monkeypatch.setenv("GME_SEA_REDO", redo)
+        for pnorm in (0, 1):
+            seq.bbme(1, 16, 16, 0, pnorm)
+            info = ctx.last_bbme_info()
+            assert info["plan"].startswith("k_exh_sea16p"), info
+            mv = seq.read_mv()
+            for p in range(21):
+                assert np.array_equal(mv[p], want[pnorm][p]), (kind, redo, pnorm, p)
+            if redo == "1" and kind == "noise":
+                assert info["redo_tiles"] > 0.8 * 21 * 180, info
+            if redo == "1" and kind == "mixed":
+                assert 0.2 * 21 * 180 < info["redo_tiles"] < 0.8 * 21 * 180, info
+            if redo == "0":
+                assert info["redo_tiles"] == 0, info
+            if kind == "flat":
+                assert info["surviving"] < 0.02 * info["patches"] and info["redo_tiles"] == 0, info
     seq.close()
+
+
+def test_redo_path_small_batches_and_window_sizes(native, monkeypatch):
+    """The redo hand-off from the one-tile kernels (small batches) and from every window size class, forced
+    for every tile (GME_SEA_REDO_FRAC=0: any listed patch makes a tile hostile) on ragged geometries."""
+    ctx = native.default_context()
+    co = c_oracle()
+    monkeypatch.setenv("GME_SEA_REDO_FRAC", "0")
+    for persist in ("0", "2"):
+        monkeypatch.setenv("GME_SEA_PERSIST", persist)
+        for (n, h, w, sw, seed) in ((5, 96, 176, 16, 3), (3, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6), (4, 80, 112, 24, 7)):
+            seq = native.Sequence(ctx, n, h, w)
+            seq.synth(seed, 0)
+            frames = [seq.read_frame(i) for i in range(n)]
+            for pn in (0, 1):
+                seq.bbme(1, 16, sw, 0, pn)
+                info = ctx.last_bbme_info()
+                assert info["redo_tiles"] > 0, (persist, info)
+                mv = seq.read_mv()
+                for p in range(n - 1):
+                    assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, 0, pn)), (persist, n, h, w, sw, pn, p)
+            seq.close()
 
 
 @pytest.mark.parametrize("pnorm", [0, 1])

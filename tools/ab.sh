@@ -1,4 +1,4 @@
-# usage: bash tools/ab.sh "<lib names under tools/microbench without libgme_ prefix>" "<bench configs>" [rounds]
+# usage: bash tools/ab.sh "<lib names under tools/microbench without libgme_ prefix>" "<bench configs>" [rounds] [extra bench args]
 # Same-box A/B of library builds (device-to-device variance is ~12 %, so only compare inside one call).
 set -e
 cd /root/repo
@@ -8,9 +8,9 @@ for r in $(seq 1 ${3:-2}); do
 for v in $1; do
   cp tools/microbench/libgme_$v.so $L
   for c in $2; do
-    echo -n "$v $c "; timeout -k 10 200 python3 bench.py --config $c --no-cpu-baseline 2>/dev/null | python3 -c "
+    echo -n "$v $c $4 "; timeout -k 10 200 python3 bench.py --config $c --no-cpu-baseline --no-pcie --no-content-sweep $4 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(round(d['value']))"
+d=json.loads(sys.stdin.read()); print(round(d['value']), d['parity']['ok'], d.get('elimination',{}).get('surviving_fraction'), d.get('elimination',{}).get('tiles_redone_by_brute_force'))"
   done
 done
 done
