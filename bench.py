@@ -482,6 +482,27 @@ def main():
                      "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": abytes},
         "parity": parity,
     }
+    if gme:
+        # the dominant kernel of the GME step is the level-2 block search (diamond: k_walk16<1>; configs[3]: the
+        # exhaustive MSE kernel): time that launch alone with HIP events on one lane's stream and rate it against the
+        # bytes it must touch (both frames once + the field)
+        lane0 = shard.lanes[0]
+        n0 = lane0.hi - lane0.lo
+        p_proc, p_sw = (0, sw) if proc == -2 else (3, 2)
+        lane0.seq.bbme(1, bs, p_sw, p_proc, 1)
+        lane0.ctx.sync()
+        lane0.ctx.timer_start()
+        for _ in range(3):
+            lane0.seq.bbme(1, bs, p_sw, p_proc, 1)
+        k_ms = lane0.ctx.timer_stop() / 3
+        kinfo = lane0.ctx.last_bbme_info()
+        kbytes = algorithmic_bytes(H, W, bs, False) * n0
+        out["roofline"].update({
+            "kernel": kinfo["plan"] + " (level-2 search of the step, timed alone on %d pairs)" % n0,
+            "kernel_ms_per_launch": k_ms, "algorithmic_bytes_per_launch": kbytes,
+            "achieved": kbytes / (k_ms * 1e-3) / 1e9, "frac": kbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "whole_step": {"ms": kernel_ms, "algorithmic_bytes": abytes, "achieved_GBps": achieved,
+                           "note": "all kernels + host solves, %d streams" % len(shard.lanes)}})
     if info.get("patches"):
         out["elimination"] = {"patches": info["patches"], "surviving": info["surviving"],
                               "surviving_fraction": info["surviving"] / info["patches"],
@@ -556,30 +577,35 @@ def main():
         # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
         # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
         n_e2e = B
-        host_frames = np.stack([seq.read_frame(i) for i in range(n_e2e + 1)])
+        chunk = int(os.environ.get("GME_BENCH_CHUNK", "128"))
+        host_frames = native.pinned_empty((n_e2e + 1, H, W))  # what a frame loader that decodes into page-locked memory hands over
+        for i in range(n_e2e + 1):
+            host_frames[i] = seq.read_frame(i)
         seq2 = native.Sequence(ctx, n_e2e + 1, H, W)          # its own sequence: upload, search, read back
-        pipelined = hasattr(seq2, "bbme_streamed")
-        if pipelined:
-            seq2.bbme_streamed(host_frames[:min(65, n_e2e + 1)], 1, bs, sw, proc, pnorm)     # first touch outside the timing
-            ctx.sync()
-            t_e = time.perf_counter()
-            mv2 = seq2.bbme_streamed(host_frames, 1, bs, sw, proc, pnorm)
-            t_e = time.perf_counter() - t_e
-        else:
-            seq2.upload(0, host_frames[:2])
-            ctx.sync()
-            t_e = time.perf_counter()
-            seq2.upload(0, host_frames)
-            seq2.bbme(1, bs, sw, proc, pnorm)
-            mv2 = seq2.read_mv(0, n_e2e)
-            t_e = time.perf_counter() - t_e
+        seq2.bbme_streamed(host_frames[:min(2 * chunk + 1, n_e2e + 1)], 1, bs, sw, proc, pnorm, chunk)     # first touch outside the timing
+        ctx.sync()
+        t_e = time.perf_counter()
+        mv2 = seq2.bbme_streamed(host_frames, 1, bs, sw, proc, pnorm, chunk)
+        t_e = time.perf_counter() - t_e
         same = bool(np.array_equal(mv2[-1], seq.read_mv(B - 1, 1)[0]) and np.array_equal(mv2[0], seq.read_mv(0, 1)[0]))
+        pageable = np.array(host_frames)                       # an ordinary NumPy stack: the HIP runtime stages it
+        t_p = time.perf_counter()
+        mv3 = seq2.bbme_streamed(pageable, 1, bs, sw, proc, pnorm, chunk)
+        t_p = time.perf_counter() - t_p
+        same = same and bool(np.array_equal(mv3, mv2))
+        ctx.sync()
+        t_c = time.perf_counter()                              # the copy alone (same bytes, page-locked source): the ceiling
+        seq2.upload(0, host_frames)
+        t_c = time.perf_counter() - t_c
         seq2.close()
+        gbs = (n_e2e + 1) * H * W / t_e / 1e9
         out["pcie_inclusive"] = {"value": n_e2e / t_e, "unit": "frame-pairs/s", "equals_resident_result": same,
-                                 "note": ("chunked upload of %d frames through a pinned staging ring on a copy stream, overlapped with the "
-                                          "search of the previous chunk, + read-back of %d fields" if pipelined else
-                                          "upload of %d frames from pageable host memory + search + read-back of %d fields; "
-                                          "each frame crosses once") % (n_e2e + 1, n_e2e)}
+                                 "host_to_device_GBps": gbs, "chunk_frames": chunk,
+                                 "copy_only": {"GBps": (n_e2e + 1) * H * W / t_c / 1e9, "pairs_per_s_if_nothing_else": n_e2e / t_c},
+                                 "from_pageable_memory": n_e2e / t_p,
+                                 "note": "gme_seq_bbme_streamed: %d frames from page-locked host memory uploaded in chunks on a copy stream "
+                                         "while the previous chunk is searched, + read-back of %d fields; each frame crosses the link once "
+                                         "(from_pageable_memory: the same call on an ordinary NumPy array)" % (n_e2e + 1, n_e2e)}
     if proc == -3:
         rows = last["rows"]
         out["sequence"] = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),

@@ -361,7 +361,11 @@ class Sequence:
         if frames.strides[2] != 1 or frames.strides[1] < self.W or frames.strides[0] < frames.strides[1] * self.H:
             frames = np.ascontiguousarray(frames)
         n = frames.shape[0]
-        out = np.empty((max(n - frame_distance, 0), int(self.H / block_size), int(self.W / block_size), 2), dtype=np.int32)
+        shape = (max(n - frame_distance, 0), int(self.H / block_size), int(self.W / block_size), 2)
+        try:                                   # page-locked result: the read-backs never hold the calling thread
+            out = pinned_empty(shape, np.int32) if shape[0] else np.empty(shape, np.int32)
+        except MemoryError:
+            out = np.empty(shape, dtype=np.int32)
         _check(self.lib.gme_seq_bbme_streamed(self.handle, _p(frames, _c_u8p), frames.strides[1], frames.strides[0], n,
                                               frame_distance, block_size, search_window, procedure, pnorm, int(chunk_frames),
                                               _p(out, _c_i32p)), self.lib)

@@ -89,8 +89,10 @@ extern "C" void gme_destroy(gme_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->redo_list) hipFree(ctx->redo_list);
+    if (ctx->stage) hipFree(ctx->stage);
     if (ctx->status) hipFree(ctx->status);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->copy_stream2) hipStreamDestroy(ctx->copy_stream2);
     if (ctx->back_stream) hipStreamDestroy(ctx->back_stream);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -444,7 +446,29 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
     GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
                 "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
     const Plane& p = s->level[2];
-    if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
+    gme_ctx* ctx = s->ctx;
+    if (row_stride == s->W && frame_stride == (int64_t)s->W * s->H && p.pitch != s->W && count > 0) {
+        // tight frames: linear copies (what the DMA engines move at link speed; 2-D copies of 720-byte rows reach
+        // ~37 GB/s) through a device staging buffer, spread into the pitched planes by k_repack
+        const size_t frame_bytes = (size_t)s->H * s->W;
+        size_t per = ((size_t)64 << 20) / frame_bytes;
+        if (per < 1) per = 1;
+        if (per > (size_t)count) per = (size_t)count;
+        if (per * frame_bytes > ctx->stage_bytes) {
+            GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->copy_stream) GME_HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+            if (ctx->stage) hipFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_bytes = 0;
+            if (hipMalloc((void**)&ctx->stage, per * frame_bytes) != hipSuccess) { gme_set_error("out of device memory (staging)"); return GME_ERR_NOMEM; }
+            ctx->stage_bytes = per * frame_bytes;
+        }
+        for (int f0 = 0; f0 < count; f0 += (int)per) {
+            const int n = count - f0 < (int)per ? count - f0 : (int)per;
+            GME_HIP_TRY(hipMemcpyAsync(ctx->stage, frames + (int64_t)f0 * frame_stride, (size_t)n * frame_bytes, hipMemcpyHostToDevice, ctx->stream));
+            int rc2 = launch_repack(ctx, ctx->stream, ctx->stage, n, s->H, s->W, p.at(first + f0), p.pitch, p.stride);
+            if (rc2) return rc2;
+        }
+    } else if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
         // planes and host frames are both back to back: one 2-D copy of count*H rows
         GME_HIP_TRY(hipMemcpy2DAsync(p.at(first), p.pitch, frames, row_stride, s->W, (size_t)s->H * count,
                                      hipMemcpyHostToDevice, s->ctx->stream));
@@ -610,6 +634,35 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     gme_drop_run(s);
+    // tight frames (the usual NumPy stack) whose rows are narrower than the plane pitch: linear copy + repack
+    const bool tight = row_stride == s->W && frame_stride == (int64_t)s->W * s->H && p.pitch != s->W;
+    // page-locked source (gme_host_alloc / hipHostMalloc)?  GME_UPLOAD_ZEROCOPY=1 lets the repack kernel read it across
+    // the link itself instead of the copy engines (measured slower: 34 vs 40 GB/s)
+    bool host_mapped = false;
+    const uint8_t* dev_view = nullptr;
+    if (tight && getenv("GME_UPLOAD_ZEROCOPY")) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, frames) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr) {
+            host_mapped = true;
+            dev_view = (const uint8_t*)at.devicePointer;
+        } else {
+            (void)hipGetLastError();                           // pageable memory: not an error
+        }
+    }
+    // GME_UPLOAD_ENGINES=2 splits every chunk over two streams (two copy engines); measured slower on MI355X boxes of
+    // this pool (22-25 GB/s against 38-39 GB/s for one stream), so one is the default
+    const bool two_engines = getenv("GME_UPLOAD_ENGINES") && atoi(getenv("GME_UPLOAD_ENGINES")) >= 2;
+    if (tight && two_engines && !ctx->copy_stream2) GME_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking));
+    if (tight && !host_mapped) {
+        const size_t want = (size_t)(chunk_frames < count ? chunk_frames : count) * s->H * s->W;
+        if (want > ctx->stage_bytes) {
+            GME_HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+            if (ctx->stage) hipFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_bytes = 0;
+            if (hipMalloc((void**)&ctx->stage, want) != hipSuccess) { gme_set_error("out of device memory (%zu bytes of staging)", want); return GME_ERR_NOMEM; }
+            ctx->stage_bytes = want;
+        }
+    }
     const int nchunks = (count + chunk_frames - 1) / chunk_frames;
     std::vector<hipEvent_t> up(nchunks, nullptr), done(nchunks, nullptr);
     auto cleanup = [&]() { for (auto e : up) if (e) hipEventDestroy(e); for (auto e : done) if (e) hipEventDestroy(e); };
@@ -624,12 +677,41 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
     STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream, gate, 0));
     STREAM_TRY(hipStreamWaitEvent(ctx->back_stream, gate, 0));
     int p_done = 0;                                            // pairs searched so far
+    int back_first = 0, back_count = 0, back_chunk = -1;       // fields of the previous chunk, still to be read back
+    auto read_back = [&]() -> bool {
+        if (back_count == 0) return true;
+        if (hipStreamWaitEvent(ctx->back_stream, done[back_chunk], 0) != hipSuccess) return false;
+        const bool ok = hipMemcpyAsync(mf_out + per * back_first, s->mv + per * back_first, per * back_count * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, ctx->back_stream) == hipSuccess;
+        back_count = 0;
+        return ok;
+    };
     for (int c = 0; c < nchunks; ++c) {
         const int f0 = c * chunk_frames, f1 = f0 + chunk_frames < count ? f0 + chunk_frames : count;
         STREAM_TRY(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
         STREAM_TRY(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
         // upload of chunk c on the copy stream: it runs while the compute stream still searches chunk c - 1
-        if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
+        if (tight && host_mapped) {
+            // page-locked frames are mapped into the device's address space: the repack kernel reads them across the
+            // link itself (thousands of loads in flight instead of one DMA queue) and writes the pitched planes
+            if (launch_repack(ctx, ctx->copy_stream, dev_view + (int64_t)f0 * frame_stride, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) { STREAM_TRY(hipErrorUnknown); }
+        } else if (tight) {
+            // one linear copy (link speed), then spread into the pitched planes on the same stream: the next chunk's
+            // copy into the staging buffer is ordered behind this repack
+            const size_t bytes = (size_t)(f1 - f0) * s->H * s->W;
+            size_t head = bytes;
+            if (two_engines && bytes >= (1u << 20)) {
+                // second half through a second stream: two copy engines share the link (one alone moved ~40 GB/s)
+                head = (bytes / 2) & ~(size_t)4095;
+                if (c > 0) STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream2, up[c - 1], 0));      // staging buffer free again
+                STREAM_TRY(hipMemcpyAsync(ctx->stage + head, frames + (int64_t)f0 * frame_stride + head, bytes - head,
+                                          hipMemcpyHostToDevice, ctx->copy_stream2));
+                STREAM_TRY(hipEventRecord(done[c], ctx->copy_stream2));                          // done[c] is re-recorded behind the kernel below
+            }
+            STREAM_TRY(hipMemcpyAsync(ctx->stage, frames + (int64_t)f0 * frame_stride, head, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (head != bytes) STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream, done[c], 0));
+            if (launch_repack(ctx, ctx->copy_stream, ctx->stage, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) { STREAM_TRY(hipErrorUnknown); }
+        } else if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
             STREAM_TRY(hipMemcpy2DAsync(p.at(f0), p.pitch, frames + (int64_t)f0 * frame_stride, row_stride, s->W,
                                         (size_t)s->H * (f1 - f0), hipMemcpyHostToDevice, ctx->copy_stream));
         } else {
@@ -638,6 +720,10 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
                                             hipMemcpyHostToDevice, ctx->copy_stream));
         }
         STREAM_TRY(hipEventRecord(up[c], ctx->copy_stream));
+        // read-back of the previous chunk's fields only now, behind this chunk's upload in program order: a copy
+        // into pageable memory may hold the calling thread until that chunk's kernel is done, and the upload
+        // queued above keeps the link busy meanwhile
+        if (!read_back()) { STREAM_TRY(hipErrorUnknown); }
         STREAM_TRY(hipStreamWaitEvent(ctx->stream, up[c], 0));
         const int p1 = f1 - fd;                                // pairs [p_done, p1) have both frames on the device now
         if (p1 > p_done) {
@@ -660,14 +746,14 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
                 return rc;
             }
             STREAM_TRY(hipEventRecord(done[c], ctx->stream));
-            STREAM_TRY(hipStreamWaitEvent(ctx->back_stream, done[c], 0));
-            STREAM_TRY(hipMemcpyAsync(mf_out + per * p_done, s->mv + per * p_done, per * (p1 - p_done) * sizeof(int32_t),
-                                      hipMemcpyDeviceToHost, ctx->back_stream));
+            back_first = p_done; back_count = p1 - p_done; back_chunk = c;
             p_done = p1;
         }
     }
+    if (!read_back()) { STREAM_TRY(hipErrorUnknown); }
 #undef STREAM_TRY
     hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->back_stream);
+    if (ctx->copy_stream2 && hipStreamSynchronize(ctx->copy_stream2) != hipSuccess) e1 = hipErrorUnknown;
     rc = ctx_finish(ctx);
     cleanup();
     if (aux) { s->sqbox_valid[2] = (count == s->N); s->sqbox_kind[2] = aux; }

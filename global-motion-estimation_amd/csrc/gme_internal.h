@@ -56,7 +56,9 @@ struct gme_ctx {
                                   // [GME_STATUS_STATS ..] per-XCD statistics of the last block-matching call (16 words apart)
     void* comm = nullptr;         // RCCL communicator (gme_comm.hip), one per context = per rank
     int comm_rank = 0, comm_world = 0;
-    hipStream_t copy_stream = nullptr, back_stream = nullptr;   // gme_seq_bbme_streamed: uploads / read-backs beside the kernels
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr, back_stream = nullptr;   // gme_seq_bbme_streamed: uploads / read-backs beside the kernels
+    uint8_t* stage = nullptr;        // device staging of tight host frames (gme_seq_bbme_streamed), repacked into the planes
+    size_t stage_bytes = 0;
     uint32_t* redo_list = nullptr;   // tiles the elimination kernels hand to the brute-force redo kernel (grown on demand)
     size_t redo_cap = 0;             // entries
     char plan[192] = "";          // kernel / tile shape / schedule the last block-matching call chose (gme_last_bbme_info)
@@ -146,6 +148,8 @@ int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
 
 // ---- gme_kernels.hip --------------------------------------------------------
 int max_grid_planes();
+int launch_repack(gme_ctx* ctx, hipStream_t stream, const uint8_t* src, int count, int H, int W, uint8_t* dst, int pitch,
+                  long long dst_stride);
 int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst);
 int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0);
 int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params,

@@ -476,7 +476,36 @@ __global__ void __launch_bounds__(256) k_sse(const uint8_t* a, long long a_strid
     if ((threadIdx.x & 63) == 0 && err) atomicAdd(&sse[pair], (unsigned long long)err);
 }
 
+// Tight host frames (row stride W) arrive as ONE linear copy per chunk -- the form the DMA engines move at link
+// speed; a 2-D copy with 720-byte rows reached 37 GB/s -- and are spread into the pitched planes here.
+__global__ void __launch_bounds__(256) k_repack(const uint8_t* src, int H, int W, uint8_t* dst, int pitch, long long dst_stride)
+{
+    const int f = blockIdx.z, y = blockIdx.y;
+    const uint8_t* s = src + ((long long)f * H + y) * W;
+    uint8_t* o = dst + (long long)f * dst_stride + (long long)y * pitch;
+    if ((W & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (pitch & 15) == 0 && (dst_stride & 15) == 0) {
+        for (int x = (blockIdx.x * 256 + threadIdx.x) * 16; x < W; x += gridDim.x * 256 * 16)
+            *(uint4*)(o + x) = *(const uint4*)(s + x);
+    } else {
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) o[x] = s[x];
+    }
+}
+
 }  // namespace
+
+int launch_repack(gme_ctx* ctx, hipStream_t stream, const uint8_t* src, int count, int H, int W, uint8_t* dst, int pitch,
+                  long long dst_stride)
+{
+    const int step = max_grid_planes();
+    for (int first = 0; first < count; first += step) {
+        const int n = count - first < step ? count - first : step;
+        const int per_row = (W & 15) == 0 ? (W / 16 + 255) / 256 : (W + 255) / 256;
+        hipLaunchKernelGGL(k_repack, dim3(per_row, H, n), dim3(256), 0, stream, src + (long long)first * H * W, H, W,
+                           dst + (long long)first * dst_stride, pitch, dst_stride);
+    }
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
 
 // Planes / pairs one launch may put in grid.y or grid.z (hardware limit 65535).  GME_MAX_GRID_PAIRS
 // lowers it so that tests reach the chunked paths with a handful of pairs.

@@ -12,9 +12,16 @@ def kname(full):
     return m.group(1) if m else full[:50]
 
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = sys.argv[1]
 needle = sys.argv[2] if len(sys.argv) > 2 else ""
 print("# source: %s (rocprofv3 --pmc <counters> --kernel-trace, separate passes)" % root)
+try:
+    import bench
+    print("# kernel_source_sha: %s" % bench.kernel_source_sha())       # bench.py emits these counters only for the same kernels
+except Exception as e:      # noqa: BLE001
+    print("# kernel_source_sha: unknown (%r)" % (e,))
 for path in sorted(glob.glob(root + "/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
     meta = {}
