@@ -561,7 +561,12 @@ int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int
     const int by_lds = (int)((160 * 1024) / (lds + 1024));                   // ... and LDS
     if (per_cu > by_lds) per_cu = by_lds;
     if (per_cu < 1) per_cu = 1;
-    const dim3 grid((unsigned)(per_cu * ctx->prop.multiProcessorCount)), block(64 * tc);
+    // a full grid costs ~30 us to dispatch even when every workgroup finds the list empty: never launch more
+    // workgroups than the list can hold items (single-pair calls: a few hundred)
+    long long groups = (long long)per_cu * ctx->prop.multiProcessorCount;
+    const long long max_items = (long long)job.pairs * tile_wg_per_pair * tr;
+    if (groups > max_items) groups = max_items;
+    const dim3 grid((unsigned)groups), block(64 * tc);
 #define REDO_LAUNCH(RR) do { if (mse) hipLaunchKernelGGL((k_exh_redo16<RR, true>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); \
                              else hipLaunchKernelGGL((k_exh_redo16<RR, false>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); } while (0)
     switch (R) {

@@ -463,14 +463,14 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         // the two BASELINE shapes (720x480 sw 16: 2x4 tiles; 1080p sw 32: 2x6 tiles) have instances with the tile
         // geometry folded in at compile time; GME_SEA_GENERIC=1 keeps the run-time form (A/B, tests)
         const bool fixed_ok = !getenv("GME_SEA_GENERIC");
-        const bool fix3 = fixed_ok && R == 3 && nv <= 6 && geometry_matches(d, 3, 2 * 16 + 4);
-        const bool fix5 = fixed_ok && R == 5 && nv <= 8 && geometry_matches(d, 5, 2 * 16 + 6);
+        const bool fix3 = fixed_ok && R == 3 && nv <= 5 && geometry_matches(d, 3, 2 * 16 + 4);
+        const bool fix5 = fixed_ok && R == 5 && nv <= 7 && geometry_matches(d, 5, 2 * 16 + 6);
         plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16p<%d,%d> tiles %dx%d persistent-%s%s grid %u lds %zu",
-                  R, nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", (fix3 || fix5) ? " geometry-fixed" : "", grid.x, lds);
+                  R, fix3 ? 5 : fix5 ? 7 : nv <= 6 ? 6 : nv <= 8 ? 8 : nv <= 12 ? 12 : 16, d.tr, d.tc, pp.dynamic ? "dynamic" : "static", (fix3 || fix5) ? " geometry-fixed" : "", grid.x, lds);
         if (fix3) {
-            hipLaunchKernelGGL((k_exh_sea16p<3, 6, 2 * 16 + 4>), grid, block, lds, ctx->stream, d);
+            hipLaunchKernelGGL((k_exh_sea16p<3, 5, 2 * 16 + 4>), grid, block, lds, ctx->stream, d);
         } else if (fix5) {
-            hipLaunchKernelGGL((k_exh_sea16p<5, 8, 2 * 16 + 6>), grid, block, lds, ctx->stream, d);
+            hipLaunchKernelGGL((k_exh_sea16p<5, 7, 2 * 16 + 6>), grid, block, lds, ctx->stream, d);
         } else
 #define SEA_LAUNCH_P(RR, NVV) hipLaunchKernelGGL((k_exh_sea16p<RR, NVV>), grid, block, lds, ctx->stream, d)
 #define SEA_LAUNCH_PN(RR) do { if (nv <= 6) SEA_LAUNCH_P(RR, 6); else if (nv <= 8) SEA_LAUNCH_P(RR, 8); \

@@ -239,16 +239,56 @@ __device__ __forceinline__ void anchor_quadrants(uint32_t mine, uint32_t* a01, u
     *a23 = q2 | (q3 << 16);
 }
 
+// LDS pitches from bank models of the reads that dominate (MI355X_MICROARCH.md, LDS: a wave's 8-byte reads are
+// served 32 lanes at a time over 64 four-byte banks, 4-byte reads over 32; lanes conflict only on different
+// addresses of one bank).
+//
+// Box-sum table pitch XQ (8-byte quads per row): phase B's lane (prow, q) reads quads (prow * R + i) * XQ + q * R + k,
+// so the 32 lanes of a half wave sit prow * R * XQ + q * R quads apart.  An odd pitch (the first choice) left a
+// two-way conflict on every one of those reads at R = 3 and a three-way one at R = 5; the pitch is now the
+// smallest one >= need with the fewest conflicts (28 and 44 quads: none).
+constexpr int box_conflicts(int xq, int R)
+{
+    int worst = 0, hits[64] = {};
+    for (int b = 0; b < 64; ++b) hits[b] = 0;
+    for (int prow = 0; prow < 8; ++prow)
+        for (int q = 0; q < 4; ++q) {
+            const int dw = 2 * ((prow * R) * xq + q * R);
+            ++hits[dw & 63]; ++hits[(dw + 1) & 63];             // distinct lanes read distinct quads here
+        }
+    for (int b = 0; b < 64; ++b) worst = hits[b] > worst ? hits[b] : worst;
+    return worst;
+}
+constexpr int pick_xq(int need, int R)
+{
+    int best = need, best_c = 1 << 30;
+    for (int x = need; x < need + 12; ++x) {
+        const int c = box_conflicts(x, R);
+        if (c < best_c) { best_c = c; best = x; }
+    }
+    return best;
+}
+
+// Window pitch (dwords).  Phase E, four lanes per patch: the lanes of a quad read the same columns of window rows
+// 4 apart, i.e. 4 * pitch dwords apart -- with pitch % 8 == 4 (the first choice, made for the brute-force kernel's
+// access pattern, which this kernel does not have) lanes 0/2 and 1/3 of every quad hit the same bank.  Phase C's two
+// probes (lane = 4 * row + dword, rows `pitch` apart) are rare and weigh little.
 constexpr int pick_pitch(int need, int R)
 {
     int best_p = need, best_c = 1 << 30;
-    for (int p = need; p < need + 33; ++p) {
-        int conflicts = 0, seen[32] = {};
+    for (int p = need; p < need + 16; ++p) {
+        int quad = 0, seen[32] = {};
         for (int i = 0; i < 32; ++i) seen[i] = 0;
-        for (int prow = 0; prow < 8; ++prow)
-            for (int q = 0; q < 4; ++q) conflicts += seen[((prow * R) * p + q * R) & 31]++;
-        if (conflicts < best_c) { best_c = conflicts; best_p = p; }
+        for (int sub = 0; sub < 4; ++sub) { quad += seen[(4 * sub * p) & 31]; ++seen[(4 * sub * p) & 31]; quad += seen[(4 * sub * p + 1) & 31]; }
+        int probe = 0;
+        for (int i = 0; i < 32; ++i) seen[i] = 0;
+        for (int row = 0; row < 8; ++row)
+            for (int dw = 0; dw < 4; ++dw) probe += seen[(row * p + dw) & 31]++;
+        // a wider row also costs staging loads per thread (rows per sweep = threads / pitch) and LDS
+        const int c = 64 * quad + probe + 2 * (p - need);
+        if (c < best_c) { best_c = c; best_p = p; }
     }
+    (void)R;
     return best_p;
 }
 
@@ -265,7 +305,7 @@ constexpr Shape shape_of(int R, int tr, int tc)
 {
     Shape s{};
     s.tr = tr; s.tc = tc;
-    s.xq = (4 * R + 4 * (tc - 1) + 2) | 1;                          // S8 quads per row, odd pitch
+    s.xq = pick_xq(4 * R + 4 * (tc - 1) + 2, R);                    // S8 quads per row
     const int need_dw = (tc - 1) * 4 + 3 * R + (R - 1) + 5;         // base + k + 4 pairs of two dwords
     s.pitch = pick_pitch(need_dw > s.xq + 2 ? need_dw : s.xq + 2, R);
     s.bytes = (size_t)make_layout(R, tr * tc, 16 * R + 15 + 16 * (tr - 1), s.pitch, s.xq, 16 * R + 8 + 16 * (tr - 1)).total * 4;
@@ -410,17 +450,23 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         trow = (int)(((unsigned long long)(unsigned)wg * d.magic_wpr) >> 40);
         bcol0 = (wg - trow * d.wg_per_row) * d.tc;
         pair = lp * 8 + xcd;
+        // Window rows through a buffer resource over the pair's `cur` plane (H * pitch bytes): rows above or below
+        // the frame give offsets outside it and the hardware range check returns 0 -- what the search wants there
+        // (bbme.py:157-162 skips such candidates; they never form keys) -- so no per-row guard or branch is left.
+        // Columns outside the plane and threads beyond the staging sweep get an offset that is out of range by itself.
         const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+        const unsigned long long cur_bits = (unsigned long long)cur;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cur_bits >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)cur_bits)),
+            (short)0, __builtin_amdgcn_readfirstlane(d.H * d.pitch), 0x00020000);
         const int gx0 = bcol0 * 16 - d.sw + 4 * dw, gy0 = trow * d.tr * 16 - d.sw + row0;
         const bool colok = row0 < d.rstep && gx0 >= 0 && gx0 < d.pitch;
-        const uint8_t* src = cur + (long long)gy0 * d.pitch + gx0;
-        const long long sstep = (long long)d.rstep * d.pitch;
+        const int off0 = colok ? gy0 * d.pitch + gx0 : (int)0x80000000;
+        const int sstep = d.rstep * d.pitch;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int gy = gy0 + u * d.rstep;
-            wv[u] = 0;
-            if (colok && row0 + u * d.rstep < d.win_rows && gy >= 0 && gy < d.H) wv[u] = *(const uint32_t*)(src + u * sstep);
-        }
+        for (int u = 0; u < NV; ++u)
+            wv[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, colok ? off0 + u * sstep : off0, 0, 0);
         an_next = 0;
         const WaveBlock wb = wave_block(d, trow, bcol0, wave);
         if (wb.ok) {
