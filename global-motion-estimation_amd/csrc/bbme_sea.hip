@@ -100,10 +100,16 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
     (void)NB;
 
     // ---- A': 8x8 box sums of the window (bbme_sea_common.h) ------------------------------------
+#if defined(SEA_ABLATE) && SEA_ABLATE >= 3
+    return false;                                          // timing-only build: staging + prep only
+#endif
     box_sums8<R>(d, win, s8, tid);
     STAMP(3);
     __syncthreads();
     STAMP(4);
+#if defined(SEA_ABLATE) && SEA_ABLATE >= 2
+    return false;                                          // timing-only build: + box sums
+#endif
 
     // ---- B: lower bounds of the wave's own block --------------------------------------------
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
@@ -174,6 +180,9 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
     }
 #endif
 
+#if defined(SEA_ABLATE) && SEA_ABLATE >= 1
+    return false;                                          // timing-only build: + bounds, UB, list (no evaluation, no result)
+#endif
     if constexpr (E4) {
         // ---- E (variant): four lanes per patch ---------------------------------------------------
         // Lane `sub` of a quad takes anchor rows 4*sub .. 4*sub+3 (R+3 window rows, 16*R QSADs); the four
@@ -227,38 +236,39 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
                 hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hi) + __builtin_bit_cast(u16x2, ohi));
                 acc[i] = ((uint64_t)hi << 32) | lo;
             }
-            if (active && sub == 0) {
+            if (active) {
+                // every lane of the quad holds the patch's R x 4 sums now; lane `sub` turns column `sub` into keys
+                // (R candidates instead of 4 R on one lane), the quad's minimum goes to the block's best key
                 const int c02 = (bcol0 + wc2) * 16, r02 = (trow * d.tr + wr2) * 16;
                 const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
                 const int lo_r2 = max(0, d.sw - r02), hi_r2 = min(NC - 1, d.H - 16 - r02 + d.sw);
                 const bool rows_inside2 = NC == 16 * R && lo_r2 == 0 && hi_r2 == NC - 1;
-                const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
+                const int ci = q2 * 4 * R + 4 * k2 + sub, ri0 = prow2 * R;
+                const uint32_t shift = (uint32_t)(sub & 1) * 16u;
                 uint32_t key = 0xFFFFFFFFu;
                 if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
-                    // whole window inside the frame: keys relative to the patch's first candidate, base added once
+                    // whole window inside the frame: keys relative to the column's first candidate, base added once
     #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4)
+                    for (int i = 0; i < R; ++i) {
+                        const uint32_t word = (sub & 2) ? (uint32_t)(acc[i] >> 32) : (uint32_t)acc[i];
+                        const uint32_t sad = __builtin_amdgcn_ubfe(word, shift, 16u);
+                        key = min(key, (sad << 13) + (uint32_t)i);
+                    }
+                    key += (uint32_t)(ci * NC + ri0);
+                } else if (ci >= lo_c && ci <= hi_c) {
     #pragma unroll
-                        for (int i = 0; i < R; ++i) {
-                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
-                            key = min(key, (sad << 13) + (uint32_t)(e4 * NC + i));
-                        }
-                    key += (uint32_t)(ci0 * NC + ri0);
-                } else {
-    #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        const int ci = ci0 + e4;
-                        if (ci < lo_c || ci > hi_c) continue;
-    #pragma unroll
-                        for (int i = 0; i < R; ++i) {
-                            const int ri = ri0 + i;
-                            if (ri < lo_r2 || ri > hi_r2) continue;
-                            const uint32_t sad = (uint32_t)(acc[i] >> (16 * e4)) & 0xFFFFu;
-                            key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
-                        }
+                    for (int i = 0; i < R; ++i) {
+                        const int ri = ri0 + i;
+                        if (ri < lo_r2 || ri > hi_r2) continue;
+                        const uint32_t word = (sub & 2) ? (uint32_t)(acc[i] >> 32) : (uint32_t)acc[i];
+                        const uint32_t sad = __builtin_amdgcn_ubfe(word, shift, 16u);
+                        key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
                     }
                 }
-                if (key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
+                // quad minimum (a disabled source lane would hand back `key` itself; quads are uniform in `active`)
+                key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+                if (sub == 0 && key != 0xFFFFFFFFu) atomicMin(&best[2 * w2], key);
             }
             __syncthreads();
         }

@@ -330,6 +330,7 @@ __device__ __forceinline__ void fix_geometry(SeaDev& d)
         d.rstep = 64 * TR * TC / s.pitch;
         d.magic_pitch = div_magic(s.pitch);
         d.magic_xq = div_magic(s.xq);
+        d.sw = 8 * R - 8;                                  // the full window of the size class: NC = 16 R, also a constant now
     }
 }
 
@@ -337,7 +338,7 @@ inline bool geometry_matches(const SeaDev& d, int R, int geo)
 {
     if (geo == 0) return true;
     const Shape s = shape_of(R, geo / 16, geo % 16);
-    return d.tr == geo / 16 && d.tc == geo % 16 && d.pitch_dw == s.pitch && d.xq == s.xq;
+    return d.tr == geo / 16 && d.tc == geo % 16 && d.pitch_dw == s.pitch && d.xq == s.xq && d.sw == 8 * R - 8;
 }
 
 inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
