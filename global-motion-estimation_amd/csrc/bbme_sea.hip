@@ -222,18 +222,15 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
                     }
                 }
             }
-            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+            // sum over the quad: plain 32-bit adds on the packed u16 pairs (a 16x16 SAD is at most 65280, so no partial
+            // sum carries into the upper half) -- they take the DPP operand directly, v_pk_add_u16 needs a move first
     #pragma unroll
             for (int i = 0; i < R; ++i) {
                 uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
-                uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-                uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
-                lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, lo) + __builtin_bit_cast(u16x2, olo));
-                hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hi) + __builtin_bit_cast(u16x2, ohi));
-                olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);            // quad_perm [2,3,0,1]
-                ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
-                lo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, lo) + __builtin_bit_cast(u16x2, olo));
-                hi = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, hi) + __builtin_bit_cast(u16x2, ohi));
+                lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);            // quad_perm [1,0,3,2]
+                hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+                lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);            // quad_perm [2,3,0,1]
+                hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
                 acc[i] = ((uint64_t)hi << 32) | lo;
             }
             if (active) {
