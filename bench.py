@@ -61,8 +61,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 QSAD_PEAK_OPS = 1024 * 1024 / 6.9e-9
 PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per bench line
 # rough C-oracle seconds per pair (one core), to size the parity sample
-ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.0, "exh1080mse": 1.2, "dia720": 0.01,
-                     "dia720mse": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15, "gme1080exh": 1.6}
+ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080mse": 1.8, "dia720": 0.01,
+                     "dia720mse": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15, "gme1080exh": 2.1}
 
 
 def algorithmic_bytes(H, W, bs, gme=False):
@@ -229,34 +229,37 @@ class Comm:
         if world == 1 and not os.environ.get("GME_BENCH_FORCE_DIST"):
             return
         backend = os.environ.get("GME_BENCH_BACKEND", "rccl")
-        if backend == "rccl":
-            try:
-                import sequence
-                sequence.comm_init(ctx, rank, world)
-                self.kind = "rccl (C ABI: gme_comm_*)"
-                return
-            except Exception as e:          # noqa: BLE001 -- say so and fall back
-                print("bench.py: C-ABI RCCL communicator failed (%r); falling back to torch.distributed" % (e,), file=sys.stderr)
-                backend = "nccl"
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        # RCCL prints a version banner on stdout when it initialises; stdout must carry the one JSON
-        # line only, so park fd 1 on stderr until the communicator exists
+        # RCCL may print a version banner on stdout when it initialises; stdout must carry the one JSON
+        # line only, so fd 1 is parked on stderr until the communicator exists
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            if backend == "nccl":
-                torch.cuda.set_device(local)
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-            dist.barrier()
+            if backend == "rccl":
+                try:
+                    import sequence
+                    sequence.comm_init(ctx, rank, world)
+                    self.kind = "rccl (C ABI: gme_comm_*)"
+                    return
+                except Exception as e:          # noqa: BLE001 -- say so and fall back
+                    print("bench.py: C-ABI RCCL communicator failed (%r); falling back to torch.distributed" % (e,), file=sys.stderr)
+                    backend = "nccl"
+            self._torch_init(backend, rank, world, local)
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+
+    def _torch_init(self, backend, rank, world, local):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.barrier()
         self.kind = "torch.distributed/" + backend
         self.device = torch.device("cuda", local) if backend == "nccl" else None
 
