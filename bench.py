@@ -590,6 +590,7 @@ def main():
         t_e = time.perf_counter()
         mv2 = seq2.bbme_streamed(host_frames, 1, bs, sw, proc, pnorm, chunk)
         t_e = time.perf_counter() - t_e
+        mv2 = mv2.copy()                                       # the next call reuses the page-locked result buffer
         same = bool(np.array_equal(mv2[-1], seq.read_mv(B - 1, 1)[0]) and np.array_equal(mv2[0], seq.read_mv(0, 1)[0]))
         pageable = np.array(host_frames)                       # an ordinary NumPy stack: the HIP runtime stages it
         t_p = time.perf_counter()

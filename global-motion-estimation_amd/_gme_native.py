@@ -362,10 +362,16 @@ class Sequence:
             frames = np.ascontiguousarray(frames)
         n = frames.shape[0]
         shape = (max(n - frame_distance, 0), int(self.H / block_size), int(self.W / block_size), 2)
-        try:                                   # page-locked result: the read-backs never hold the calling thread
-            out = pinned_empty(shape, np.int32) if shape[0] else np.empty(shape, np.int32)
-        except MemoryError:
-            out = np.empty(shape, dtype=np.int32)
+        # page-locked result (the read-backs never hold the calling thread), kept with the sequence: pinning
+        # 22 MB takes several milliseconds, more than the search of 2048 pairs.  The array returned is this
+        # buffer: copy it if it has to outlive the next bbme_streamed() call on the same sequence.
+        out = getattr(self, "_stream_out", None)
+        if out is None or out.shape != shape:
+            try:
+                out = pinned_empty(shape, np.int32) if shape[0] else np.empty(shape, np.int32)
+            except MemoryError:
+                out = np.empty(shape, dtype=np.int32)
+            self._stream_out = out
         _check(self.lib.gme_seq_bbme_streamed(self.handle, _p(frames, _c_u8p), frames.strides[1], frames.strides[0], n,
                                               frame_distance, block_size, search_window, procedure, pnorm, int(chunk_frames),
                                               _p(out, _c_i32p)), self.lib)
