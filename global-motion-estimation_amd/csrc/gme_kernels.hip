@@ -52,15 +52,13 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long s
     for (int dy = 0; dy < 5; ++dy) {
         const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch + 2 * x - 4;
         const u32x4_a4 v = *(const u32x4_a4*)row;
-        const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
-        int t[16];
+        // output p takes bytes 2+2p .. 6+2p of the 16: the first four through v_dot4 against the taps (1 4 6 4),
+        // the fifth (weight 1) by one bit-field extract
+        const uint32_t w4[4] = { __builtin_amdgcn_alignbyte(v.y, v.x, 2u), v.y, __builtin_amdgcn_alignbyte(v.z, v.y, 2u), v.z };
+        const uint32_t last[4] = { (v.y >> 16) & 0xFFu, v.z & 0xFFu, (v.z >> 16) & 0xFFu, v.w & 0xFFu };
 #pragma unroll
-        for (int b = 0; b < 16; ++b) t[b] = (wds[b >> 2] >> (8 * (b & 3))) & 0xFF;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {                      // taps of output p start at byte 2 + 2p
-            const int h = t[2 + 2 * p] + 4 * t[3 + 2 * p] + 6 * t[4 + 2 * p] + 4 * t[5 + 2 * p] + t[6 + 2 * p];
-            acc[p] += k[dy] * h;
-        }
+        for (int p = 0; p < 4; ++p)
+            acc[p] += k[dy] * (int)__builtin_amdgcn_udot4(w4[p], 0x04060401u, last[p], false);
     }
     *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) |
                     ((uint32_t)((acc[2] + 128) >> 8) << 16) | ((uint32_t)((acc[3] + 128) >> 8) << 24);

@@ -458,3 +458,61 @@ def test_streamed_upload_equals_resident(native, pinned):
     with pytest.raises(IndexError):
         seq.bbme_streamed(frames[:1], 1, 16, 16, 0, 0)
     seq.close()
+
+
+def test_roadmap_models_and_heuristics(native, tmp_path, capsys):
+    """The authors' roadmap (recap_future_updates.md:9-14) on the device pipeline -- EXTENSIONS, self-consistency
+    only: the model solves against least squares on the device's own inlier blocks, a warped scene where the
+    similarity model must beat translation, the parameter heuristics and the unified CLI."""
+    import gme_cli
+    import motion
+    import roadmap
+    import synth
+    from PIL import Image
+    ctx = native.default_context()
+    prev, cur = synth.frame(1234, 0, 480, 720), synth.frame(1234, 1, 480, 720)
+    aff = roadmap.global_motion_estimation(prev, cur, "affine")
+    np.testing.assert_allclose(aff, motion.global_motion_estimation(prev, cur), rtol=0, atol=0)     # the default path itself
+    for model in ("translation", "similarity"):
+        p = roadmap.global_motion_estimation(prev, cur, model)
+        assert abs(p[0] - 5) < 0.2 and abs(p[3] + 3) < 0.2, (model, p)                             # the camera pan of the scene
+    # level-2 solve against least squares on the stage the device read back
+    seq = native.Sequence.from_frames(ctx, [prev, cur])
+    params = roadmap.estimate_sequence(seq, 1, "similarity")[0]
+    st = seq.gme_read_stage(2, 0)
+    i, j = np.nonzero(~st["mask"])
+    x, y = 4.0 * i, 4.0 * j
+    dx, dy = st["gt"][i, j, 0].astype(float), st["gt"][i, j, 1].astype(float)
+    D = np.concatenate([np.stack([np.ones_like(x), 0 * x, y, -x], 1), np.stack([0 * x, np.ones_like(x), x, y], 1)])
+    th = np.linalg.lstsq(D, np.concatenate([dx, dy]), rcond=None)[0]              # (a0, b0, zoom, rotation)
+    np.testing.assert_allclose(params, [th[0], -th[3], th[2], th[1], th[2], th[3]], rtol=1e-6, atol=1e-8)
+    seq.close()
+    # a zooming scene (x1.025 about the centre, small enough for the diamond walks to follow): the similarity model
+    # reports the zoom -- column displacement 0.025 px per pixel = 0.1 per unit of the fit's y = 4 j at bs 16 -- and
+    # (almost) no rotation, translation reports neither
+    yy, xx = np.mgrid[0:240, 0:320].astype(np.float64)
+    canvas = synth.canvas(7)
+
+    def view(scale):
+        sy = np.clip(np.rint(420 + (yy - 120) / scale), 0, 2047).astype(int)
+        sx = np.clip(np.rint(560 + (xx - 160) / scale), 0, 4095).astype(int)
+        return np.ascontiguousarray(canvas[sy, sx])
+    a, b = view(1.0), view(1.025)
+    sim = roadmap.global_motion_estimation(a, b, "similarity")
+    assert 0.05 < sim[2] < 0.15 and sim[2] == sim[4] and abs(sim[1]) < 0.03 and sim[1] == -sim[5], sim
+    tra = roadmap.global_motion_estimation(a, b, "translation")
+    assert tra[1] == tra[2] == tra[4] == tra[5] == 0.0
+    aff = roadmap.global_motion_estimation(a, b, "affine")
+    assert abs(aff[2] - sim[2]) < 0.05 and abs(aff[4] - sim[4]) < 0.05, (aff, sim)
+    # heuristics: the slides' block size for this frame size (docs/presentation/main.tex:426), a window that covers the pan
+    s = roadmap.suggest_parameters(prev, cur)
+    assert s["block_size"] == 24 and 8 <= s["search_window"] <= 16 and 0.1 <= s["outlier_fraction"] <= 0.5, s
+    assert roadmap.suggest_parameters(a, a)["search_window"] <= 8          # static scene (the diamond clamp quirk moves the last block row/column by 1)
+    # unified CLI on a frame directory
+    d = tmp_path / "clip"
+    d.mkdir()
+    for k, f in enumerate((prev, cur)):
+        Image.fromarray(f).save(str(d / ("%d.png" % k)))
+    capsys.readouterr()
+    out = gme_cli.main(["suggest", "-p", str(d), "-fi", "1"])
+    assert out == s and "block_size: 24" in capsys.readouterr().out

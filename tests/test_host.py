@@ -264,3 +264,57 @@ def test_bench_helpers():
     assert bench.host_content("flat", 2, 32, 48)[0].min() == 128
     assert len(bench.kernel_source_sha()) == 16
     assert bench.byte_ops_per_pair(480, 720, 16, 16) == 2891044 * 256
+
+
+def test_roadmap_model_solves_match_least_squares():
+    """roadmap.solve_model (extension, recap_future_updates.md:9-12): from the normal-equation sums alone the
+    translation / similarity / affine solves equal np.linalg.lstsq on the underlying block vectors."""
+    import roadmap
+    rng = np.random.default_rng(12)
+    rows = []
+    truth = []
+    for trial in range(6):
+        h, w = 15 + trial, 22 + 2 * trial
+        i, j = np.mgrid[0:h, 0:w]
+        x, y = (4.0 * i).ravel(), (4.0 * j).ravel()            # motion.py:254-255
+        a0, b0, a, b = rng.normal(0, 3), rng.normal(0, 3), rng.normal(0, 0.01), rng.normal(0, 0.01)
+        dx = np.rint(a0 - b * x + a * y + rng.normal(0, 0.3, x.size))     # x: row coordinate, dx: column displacement
+        dy = np.rint(b0 + a * x + b * y + rng.normal(0, 0.3, x.size))
+        wgt = 1.0 / (h * 16 * w * 16)
+        A = np.stack([np.ones_like(x), x, y], axis=1)
+        F = (A.T @ A) * wgt
+        rows.append(np.concatenate([F.ravel(), (A.T @ dx) * wgt, (A.T @ dy) * wgt]))
+        truth.append((x, y, dx, dy))
+    rows = np.array(rows)
+    aff = roadmap.solve_model(rows, "affine")
+    tra = roadmap.solve_model(rows, "translation")
+    sim = roadmap.solve_model(rows, "similarity")
+    for k, (x, y, dx, dy) in enumerate(truth):
+        A = np.stack([np.ones_like(x), x, y], axis=1)
+        want = np.concatenate([np.linalg.lstsq(A, dx, rcond=None)[0], np.linalg.lstsq(A, dy, rcond=None)[0]])
+        np.testing.assert_allclose(aff[k], want, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(tra[k], [dx.mean(), 0, 0, dy.mean(), 0, 0], rtol=1e-10, atol=1e-12)
+        D = np.concatenate([np.stack([np.ones_like(x), 0 * x, y, -x], 1), np.stack([0 * x, np.ones_like(x), x, y], 1)])
+        th = np.linalg.lstsq(D, np.concatenate([dx, dy]), rcond=None)[0]          # (a0, b0, zoom, rotation)
+        np.testing.assert_allclose(sim[k], [th[0], -th[3], th[2], th[1], th[2], th[3]], rtol=1e-8, atol=1e-10)
+        assert sim[k][2] == sim[k][4] and sim[k][1] == -sim[k][5]
+    with pytest.raises(ValueError):
+        roadmap.solve_model(rows, "perspective")
+    with pytest.raises(np.linalg.LinAlgError):
+        roadmap.solve_model(np.zeros((1, 15)), "similarity")
+    with pytest.raises(np.linalg.LinAlgError):
+        roadmap.solve_model(np.zeros((1, 15)), "translation")
+
+
+def test_cli_lists_commands(capsys):
+    import gme_cli
+    with pytest.raises(SystemExit):
+        gme_cli.main(["--help"])
+    out = capsys.readouterr().out
+    for word in ("bbme", "results", "suggest", "info"):
+        assert word in out
+    with pytest.raises(SystemExit):
+        gme_cli.main(["bbme"])                     # -p and -fi are required, as upstream
+    gme_cli.main(["info"])
+    out = capsys.readouterr().out
+    assert "three-step" in out and "similarity" in out and "device:" in out
