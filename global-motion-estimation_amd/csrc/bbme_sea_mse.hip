@@ -63,7 +63,7 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
 }
 
 // Phases A' .. F of one tile (entry conditions as tile_phases() of bbme_sea.hip, plus a2s[] filled).
-template <int R, bool E4>
+template <int R, int LPPT>
 __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                 uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid, int tile_id)
 {
@@ -151,12 +151,12 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
     // ---- E: LPP lanes per listed patch; lane `sub` takes anchor rows AR*sub .. AR*sub+AR-1 (R+AR-1 window
     // rows), the partial dot products are added inside the quad with DPP moves.  Four lanes per patch
     // repeat some v_alignbyte work but put four times as many waves on the (long) evaluation.
-    constexpr int LPP = E4 ? 4 : 1, AR = 16 / LPP;
+    constexpr int LPP = LPPT, AR = 16 / LPP;
     const int n = (int)*count;
     const uint32_t* tab = d.sqbox + (long long)pair * d.sqbox_stride;
     for (int base = 0; base < n; base += T / LPP) {
         const int e = base + tid / LPP;
-        const int sub = E4 ? (lane & 3) : 0;
+        const int sub = lane & (LPP - 1);
         bool active = e < n;
         uint32_t ent = 0;
         if (active) {
@@ -212,13 +212,13 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
                     for (int e4 = 0; e4 < 4; ++e4) asm volatile("" : "+v"(acc[i][e4]));
             }
         }
-        if (E4) {                                          // quads are uniform in `active` (one entry per quad)
+        if (LPP > 1) {                                     // lane groups are uniform in `active` (one entry per group)
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     acc[i][e4] += SEA_DPP(acc[i][e4], 0xB1);                     // quad_perm [1,0,3,2]
-                    acc[i][e4] += SEA_DPP(acc[i][e4], 0x4E);                     // quad_perm [2,3,0,1]
+                    if (LPP > 2) acc[i][e4] += SEA_DPP(acc[i][e4], 0x4E);        // quad_perm [2,3,0,1]
                 }
         }
         if (active && sub == 0) {
@@ -273,7 +273,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
     return false;
 }
 
-template <int R, bool E4>
+template <int R, int LPPT>
 struct MseTile {
     struct Pre { uint32_t a01, a23, mine2; };
     static __device__ __forceinline__ Pre prep(const SeaDev&, uint32_t* lds, const Layout& L, int wave, int lane, bool wave_ok, uint32_t mine)
@@ -291,11 +291,11 @@ struct MseTile {
     static __device__ __forceinline__ bool phases(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                   uint32_t mine, const Pre& p, int tid, int tile_id)
     {
-        return tile_phases_mse<R, E4>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, p.mine2, tid, tile_id);
+        return tile_phases_mse<R, LPPT>(d, lds, L, pair, trow, bcol0, mine, p.a01, p.a23, p.mine2, tid, tile_id);
     }
 };
 
-template <int R, bool E4>
+template <int R, int LPPT>
 __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
@@ -312,19 +312,22 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
         const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)(wb.brow * 16) * d.pitch + wb.bcol * 16;
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
     }
-    const typename MseTile<R, E4>::Pre pre = MseTile<R, E4>::prep(d, lds, L, wave, lane, wb.ok, mine);
+    const typename MseTile<R, LPPT>::Pre pre = MseTile<R, LPPT>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (threadIdx.x == 0) lds[L.count] = 0;
     __syncthreads();
-    MseTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
+    MseTile<R, LPPT>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
     if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
 }
 
+#ifndef SEA_MSE_LPP
+#define SEA_MSE_LPP 1
+#endif
 template <int R, int NV, int GEO = 0>
 __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 6)) k_exh_sea16p_mse(SeaDev d)
 {
     extern __shared__ uint32_t lds[];
     fix_geometry<R, GEO>(d);
-    persistent_tiles<NV, MseTile<R, false>>(d, lds, layout_of(d, R));
+    persistent_tiles<NV, MseTile<R, SEA_MSE_LPP>>(d, lds, layout_of(d, R));
 }
 
 }  // namespace
@@ -404,8 +407,8 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     plan_note(ctx, (long long)job.pairs * nbr * nbc * 64 * R, "k_exh_sea16_mse<%d> tiles %dx%d one-tile grid %ux%ux%u lds %zu", R, d.tr, d.tc,
               grid.x, grid.y, grid.z, lds);
         const bool e4 = getenv("GME_SEA_E4") ? atoi(getenv("GME_SEA_E4")) != 0 : false;   // measured: four lanes per patch lose 9 % here (repeated v_alignbyte work)
-#define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16_mse<RR, true>), grid, block, lds, ctx->stream, d); \
-                            else hipLaunchKernelGGL((k_exh_sea16_mse<RR, false>), grid, block, lds, ctx->stream, d); } while (0)
+#define SEA_LAUNCH(RR) do { if (e4) hipLaunchKernelGGL((k_exh_sea16_mse<RR, 4>), grid, block, lds, ctx->stream, d); \
+                            else hipLaunchKernelGGL((k_exh_sea16_mse<RR, 1>), grid, block, lds, ctx->stream, d); } while (0)
         switch (R) {
         case 1: SEA_LAUNCH(1); break;
         case 2: SEA_LAUNCH(2); break;
