@@ -336,7 +336,7 @@ def main():
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
     # not matter and concurrent persistent kernels only contend: 17.5 k pairs/s on one stream, 15 k on three)
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "3"))
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "4"))     # 1/2/3/4/6 streams: 396/381/412/424/355 k pairs/s (gme720)
     shard = seq = None
     if proc == -3:
         import sequence
