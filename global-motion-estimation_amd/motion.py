@@ -48,15 +48,33 @@ def _solve_batch(sums):
     return np.concatenate([ax, ay], axis=1)
 
 
-def _fit_pair(previous, current, old_parameters, fraction):
+_pair_cache = __import__("threading").local()
+
+
+def _pair_sequence(previous, current):
+    """A two-frame device sequence holding (previous, current) for the single-pair functions.  It is kept per
+    thread and per frame shape: allocating the planes, pyramids and stage buffers anew for every call cost more
+    than the kernels of a small pair (the reference's per-pair functions are called in loops, results.py:41-59)."""
+    previous, current = _native.as_frame(previous, "previous"), _native.as_frame(current, "current")
+    if previous.shape != current.shape:
+        raise AssertionError("previous and current differ in shape (bbme.py:59)")
     ctx = _native.default_context()
-    seq = _native.Sequence.from_frames(ctx, [previous, current])
-    try:
-        seq.bbme(1, int(BBME_BLOCK_SIZE), 2, 3, 1)                     # motion.py:224-229 (diamond, MSE)
-        p = np.asarray(old_parameters).astype(np.float64).reshape(1, 6)
-        return _solve(seq.gme_fit(-1, p, fraction)[0])
-    finally:
-        seq.close()
+    ent = getattr(_pair_cache, "entry", None)
+    if ent is None or ent[0] != previous.shape or ent[1].handle is None or ent[1].ctx is not ctx:
+        if ent is not None:
+            ent[1].close()
+        ent = (previous.shape, _native.Sequence(ctx, 2, previous.shape[0], previous.shape[1]))
+        _pair_cache.entry = ent
+    seq = ent[1]
+    seq.upload(0, np.stack([previous, current]))
+    return seq
+
+
+def _fit_pair(previous, current, old_parameters, fraction):
+    seq = _pair_sequence(previous, current)
+    seq.bbme(1, int(BBME_BLOCK_SIZE), 2, 3, 1)                         # motion.py:224-229 (diamond, MSE)
+    p = np.asarray(old_parameters).astype(np.float64).reshape(1, 6)
+    return _solve(seq.gme_fit(-1, p, fraction)[0])
 
 
 def best_affine_parameters(previous, current):
@@ -117,12 +135,7 @@ def estimate_sequence(seq, frame_distance=1, procedure=3, search_window=2):
 
 def global_motion_estimation(previous, current):
     """motion.py:109-136 -> float64[6] = [a0, a1, a2, b0, b1, b2] at full resolution."""
-    ctx = _native.default_context()
-    seq = _native.Sequence.from_frames(ctx, [previous, current])
-    try:
-        return estimate_sequence(seq, 1)[0]
-    finally:
-        seq.close()
+    return estimate_sequence(_pair_sequence(previous, current), 1)[0]
 
 
 def compensate_frame(frame, motion_field):
