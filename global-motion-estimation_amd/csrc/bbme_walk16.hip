@@ -24,12 +24,13 @@ struct WalkDev {
     const uint8_t* cur;
     long long plane_stride;
     int pairs, H, W, pitch, sw, procedure;
-    int nbr, nbc;
+    int nbr, nbc, bpw;
     int32_t* mf;
     int* status;
 };
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint16_t u16_u __attribute__((aligned(1)));
 
 constexpr unsigned INF32 = 0xFFFFFFFFu;
@@ -38,6 +39,15 @@ __device__ __forceinline__ int clamp_ref(int v, int hi)   // min(max(v, 0), hi),
 {
     const int t = v > 0 ? v : 0;
     return t < hi ? t : hi;
+}
+
+// clamp_ref for per-lane values as one instruction (v_med3_i32 of v, 0, hi; hi >= 0 on every path that gets here:
+// bbme_check_args refuses diamond searches on frames without room for a block)
+__device__ __forceinline__ int clamp_med3(int v, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
 }
 
 // sum over the 8 lanes of a group (lanes 8g .. 8g+7) with DPP moves: xor 1, xor 2 inside
@@ -89,33 +99,54 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
 // odd, so the 8 lanes of a group -- 2 rows apart -- hit 8 different banks).  A candidate block
 // (rr, cc) can be served from it when 0 <= rr - wr0 <= WIN_ROWS - 16 and 0 <= cc - wc0 <= WIN_SPAN.
 constexpr int WIN_ROWS = 40, WIN_DW = 12, WIN_PITCH = 13, WIN_SPAN = 4 * (WIN_DW - 5) + 3;
+constexpr int WIN_ALLOC = 43 * WIN_PITCH;      // staging moves 128 sixteen-byte segments (2 per lane, no idle lanes): 42 2/3 rows
+
+// Window staging in two halves, so that the loads of a block's first window can be in flight while the
+// wave still walks the block before it: 3 sixteen-byte segments per row, 2 segments per lane.
+__device__ __forceinline__ void window_load(uint32_t (&v)[2][4], const uint8_t* cur, int pitch, int H, int wr0, int wc0,
+                                            int lane)
+{
+    // Branch-free through a buffer resource over the plane: whatever lies outside [0, H * pitch) -- rows above or
+    // below the frame -- reads as 0.  The window never starts left of the frame (wc0 >= 0: a 16-byte load whose
+    // first dword lies before the plane is dropped as a whole, valid bytes included); columns right of a
+    // row wrap into the next row, which is harmless: candidates are clamped into the frame, so window cells
+    // outside it are never part of a cost.  Without branches the loads of the NEXT block's window stay in flight
+    // (no s_waitcnt between them and the walk of the current block).
+    // The range is 12 bytes longer than the plane so that a 16-byte segment starting in the last 12 bytes of the
+    // last row is not dropped as a whole; every plane has a guard row behind it (plane_alloc, gme_bbme_u8).
+    const uint64_t base = (uint64_t)cur;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)base)),
+        (short)0, __builtin_amdgcn_readfirstlane(H * pitch + 12), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int seg = lane + 64 * it;
+        const int row = seg / 3, s4 = seg - row * 3;
+        const int off = (wr0 + row) * pitch + wc0 + 16 * s4;                 // negative = far out of range as unsigned
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
+    }
+}
+
+__device__ __forceinline__ void window_store(uint32_t* lds, const uint32_t (&v)[2][4], int lane)
+{
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int seg = lane + 64 * it;                 // 128 segments = the 40 window rows + 8 spare segments (WIN_ALLOC)
+        const int row = seg / 3, s4 = seg - row * 3;
+        uint32_t* o = lds + row * WIN_PITCH + 4 * s4;
+        o[0] = v[it][0]; o[1] = v[it][1]; o[2] = v[it][2]; o[3] = v[it][3];
+    }
+    __builtin_amdgcn_wave_barrier();                    // LDS ops of one wave complete in order
+}
 
 __device__ __forceinline__ void stage_walk_window(uint32_t* lds, const uint8_t* cur, int pitch, int H, int wr0,
                                                   int wc0, int lane)
 {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int seg = lane + 64 * it;                 // 3 sixteen-byte segments per row
-        if (seg < WIN_ROWS * 3) {
-            const int row = seg / 3, s4 = seg - row * 3;
-            const int gy = wr0 + row, gx = wc0 + 16 * s4;
-            uint32_t v[4] = { 0, 0, 0, 0 };
-            if (gy >= 0 && gy < H) {
-                const uint8_t* p = cur + (long long)gy * pitch + gx;
-                if (gx >= 0 && gx + 16 <= pitch) {
-                    const u32x4_a4 t = *(const u32x4_a4*)p;
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (gx + 4 * q >= 0 && gx + 4 * q < pitch) v[q] = *(const uint32_t*)(p + 4 * q);
-                }
-            }
-            uint32_t* o = lds + row * WIN_PITCH + 4 * s4;
-            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();                    // LDS ops of one wave complete in order
+    uint32_t v[2][4];
+    window_load(v, cur, pitch, H, wr0, wc0, lane);
+    window_store(lds, v, lane);
 }
 
 template <int PNORM>
@@ -124,9 +155,14 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
 {
     unsigned part = 0;
     if (valid) {
-        const int bc = cc - wc0;
-        const uint32_t sh = (uint32_t)bc & 3u;
-        const uint32_t* p = lds + __mul24(rr - wr0 + lrow, WIN_PITCH) + (bc >> 2);    // row < 40: 24-bit multiply (v_mul_lo_u32 is quarter rate)
+        // window origin columns are multiples of 4 (wc0 = ... & ~3), so the byte shift is cc & 3 and the dword column
+        // (cc & ~3) - wc0; everything wave-uniform (window origin, LDS base) folds into one scalar: mad24 + and + add3
+        const uint32_t sh = (uint32_t)cc & 3u;
+        const int sbase = -wr0 * (4 * WIN_PITCH) - wc0;
+        static_assert(4 * WIN_PITCH == 52, "row pitch in bytes is spelled out in the asm below");
+        int rowoff;                                              // valid candidates have 0 <= rr < 2^24; asm keeps the compiler
+        asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow * (4 * WIN_PITCH)));   // from re-deriving a v_mul_lo_u32
+        const uint32_t* p = (const uint32_t*)((const char*)lds + (rowoff + ((cc & ~3) + sbase)));
         uint32_t l0[5], l1[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[WIN_PITCH + j]; }
@@ -140,44 +176,64 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
 #pragma unroll
             for (int j = 0; j < 8; ++j) part = __builtin_amdgcn_sad_u8(a[j], b[j], part);
         } else {
-            unsigned bb = 0, ab = 0;
+            unsigned bb = aa, ab = 0;                      // sum a^2 rides in the b^2 chain: no separate add
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
                 ab = __builtin_amdgcn_udot4(a[j], b[j], ab, false);
             }
-            part = aa + bb - 2u * ab;
+            // bb - 2 ab in one op (ab < 2^23).  The s_nop covers the dot4 -> VALU read wait states that the
+            // compiler's hazard pass only inserts for consumers it can see (it gave the same 3 to its own v_lshlrev here)
+            asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
         }
     }
     part = group8_sum(part);
     return valid ? part : INF32;
 }
 
-template <int PNORM>
-__global__ void __launch_bounds__(256) k_walk16(WalkDev d)
+// What a wave fetches ahead for a block: its 2 anchor rows per lane and, for the diamond search (whose first
+// window position depends on the block alone), the lane's share of that window.
+struct WalkPre {
+    uint4 a0, a1;
+    uint32_t w[2][4];
+};
+
+// first window of a diamond walk: the one PATTERN_MIN would stage around the clamped block origin
+__device__ __forceinline__ void first_window(const WalkDev& d, int blk, int& wr0, int& wc0)
 {
-    __shared__ uint32_t win_all[4][WIN_ROWS * WIN_PITCH];
-    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nblk = d.nbr * d.nbc;
-    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b serves pair
-    // (b/8/WPP)*8 + b%8 -- all blocks of a frame pair walk through one XCD's L2
-    const int wpp = (nblk + 3) >> 2;
-    const int pair = ((int)blockIdx.x / 8 / wpp) * 8 + ((int)blockIdx.x & 7);
-    const int blk = (((int)blockIdx.x >> 3) % wpp) * 4 + wave_in_wg;
-    if (pair >= d.pairs || blk >= nblk) return;                // wave-uniform
+    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
+    wr0 = clamp_ref(r0, d.H - 17) - (WIN_ROWS - 16) / 2;
+    wc0 = max(0, (clamp_ref(c0, d.W - 17) - (WIN_SPAN - 3) / 2) & ~3);          // never left of the frame, see window_load
+}
+
+__device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int pair, int blk)
+{
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
+    const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)(r0 + (lane & 7) * 2) * d.pitch + c0;
+    f.a0 = *(const uint4*)ap; f.a1 = *(const uint4*)(ap + d.pitch);              // 16-byte aligned
+    if (d.procedure == GME_SEARCH_DIAMOND) {
+        int wr0, wc0;
+        first_window(d, blk, wr0, wc0);
+        window_load(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, wr0, wc0, lane);
+    }
+}
+
+// one 16x16 block of one frame pair, walked by one wave
+template <int PNORM>
+__device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, const int blk, const int nblk, uint32_t* win,
+                                           const WalkPre& pre)
+{
     const long long gid = (long long)pair * nblk + blk;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, lrow = (lane & 7) * 2;           // group = candidate slot, lane = 2 block rows
     const int H = d.H, W = d.W, pitch = d.pitch;
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
-    const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)(r0 + lrow) * pitch + c0;
 
     uint32_t a[8];
-    {
-        const uint4 a0 = *(const uint4*)ap, a1 = *(const uint4*)(ap + pitch);     // 16-byte aligned
-        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-    }
+    a[0] = pre.a0.x; a[1] = pre.a0.y; a[2] = pre.a0.z; a[3] = pre.a0.w;
+    a[4] = pre.a1.x; a[5] = pre.a1.y; a[6] = pre.a1.z; a[7] = pre.a1.w;
     unsigned aa = 0;
     if (PNORM == 1) {
 #pragma unroll
@@ -188,9 +244,12 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
     // Candidates are served from the LDS window; when some fall outside it the window is moved
     // (centred on their bounding box) and, if the pattern is wider than the window (first steps
     // of three-step / 2-D log), this round reads global memory directly.
-    uint32_t* win = win_all[wave_in_wg];
     int wr0 = 0, wc0 = 0;
     bool have_win = false;
+#if defined(WALK_ABLATE) && WALK_ABLATE == 1      // timing experiments only (tools/build_variant.sh): anchors loaded, nothing else
+    if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)(a[0] + a[7] + aa) >> 30; o[1] = 0; }
+    return;
+#endif
 #define EVAL8(n, CR, CC, OK, COST)                                                                   \
     do {                                                                                             \
         int rmin_ = 1 << 30, rmax_ = -(1 << 30), cmin_ = 1 << 30, cmax_ = -(1 << 30);                \
@@ -202,7 +261,7 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
                          cmax_ <= wc0 + WIN_SPAN)) {                                                 \
             if (rmax_ - rmin_ <= WIN_ROWS - 16 && cmax_ - cmin_ <= WIN_SPAN - 3) {                   \
                 wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                 \
-                wc0 = (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3;                           \
+                wc0 = max(0, (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3);                   \
                 stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                               \
                 have_win = true;                                                                     \
             } else lds_ok_ = false;                                                                  \
@@ -223,6 +282,9 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };   // LDSP minus its centre
         int pr = r0, pc = c0;
         unsigned centre_cost;
+        first_window(d, blk, wr0, wc0);                 // fetched ahead by walk_prefetch
+        window_store(win, pre.w, lane);
+        have_win = true;
         // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns
         int my_dr = 0, my_dc = 0, my_sr = 0, my_sc = 0;
         const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
@@ -232,7 +294,7 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
         for (int k = 0; k < 4; ++k) if (grp == k) { my_sr = sdr[k]; my_sc = sdc[k]; }
         // Winner of a pattern without leaving the vector unit: every lane of group k holds candidate k's
         // cost, key = cost << 3 | k (cost < 2^24), minimum over the 8 groups by one DPP rotate inside
-        // each 16-lane row plus four v_readlane.  Only a key whose cost is strictly below the centre's
+        // each 16-lane row, two row broadcasts and one v_readlane.  Only a key whose cost is strictly below the centre's
         // moves the centre (bbme.py:507-510: first strict minimum, the centre is candidate 0); the
         // winner's offset comes out of nibble tables, so no per-candidate scalar position is needed.
 #define PATTERN_MIN(n, SPAN, RRV, CCV, KMIN)                                                          \
@@ -242,20 +304,21 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
            the window still holds it (conservative: a miss only costs a re-stage) */               \
         const int prc_ = clamp_ref(pr, maxr), pcc_ = clamp_ref(pc, maxc);                            \
         if (!(have_win && (unsigned)(prc_ - (SPAN) - wr0) <= (unsigned)(WIN_ROWS - 16 - 2 * (SPAN)) && \
-              (unsigned)(pcc_ - (SPAN) - wc0) <= (unsigned)(WIN_SPAN - 2 * (SPAN)))) {               \
+              (unsigned)(max(pcc_ - (SPAN), 0) - wc0) <= (unsigned)(WIN_SPAN - 2 * (SPAN)))) {       \
             const int rmin_ = clamp_ref(pr - (SPAN), maxr), rmax_ = clamp_ref(pr + (SPAN), maxr);    \
             const int cmin_ = clamp_ref(pc - (SPAN), maxc), cmax_ = clamp_ref(pc + (SPAN), maxc);    \
             wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                     \
-            wc0 = (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3;                               \
+            wc0 = max(0, (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3);                       \
             stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
             have_win = true;                                                                         \
         }                                                                                            \
         const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, wr0, wc0, RRV, CCV, grp < (n), lrow);  \
         unsigned key_ = grp < (n) ? (c_ << 3) | (unsigned)grp : INF32;                               \
         key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x128, 0xF, 0xF, false)); /* row_ror 8 */ \
-        const unsigned k0_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 0), k1_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 16); \
-        const unsigned k2_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 32), k3_ = (unsigned)__builtin_amdgcn_readlane((int)key_, 48); \
-        KMIN = min(min(k0_, k1_), min(k2_, k3_));                                                    \
+        /* rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31): lane 63 ends with the minimum */ \
+        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x142, 0xA, 0xF, false)); \
+        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x143, 0xC, 0xF, false)); \
+        KMIN = (unsigned)__builtin_amdgcn_readlane((int)key_, 63);                                   \
     } while (0)
         {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once
             const int rr0 = clamp_ref(pr, maxr), cc0 = clamp_ref(pc, maxc);
@@ -263,9 +326,13 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
             PATTERN_MIN(1, 0, rr0, cc0, k0);
             centre_cost = k0 >> 3;
         }
+#if defined(WALK_ABLATE) && WALK_ABLATE == 2      // first window staged + centre evaluated
+        if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)centre_cost >> 30; o[1] = 0; }
+        return;
+#endif
         int it = 0;
         for (;;) {
-            const int rrv = clamp_ref(pr + my_dr, maxr), ccv = clamp_ref(pc + my_dc, maxc);
+            const int rrv = clamp_med3(pr + my_dr, maxr), ccv = clamp_med3(pc + my_dc, maxc);
             unsigned kmin;
             PATTERN_MIN(8, 2, rrv, ccv, kmin);
             // candidate 0 of the pattern is the clamped centre itself
@@ -282,10 +349,14 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
             if (done) break;
             if (++it > cap) { overrun = true; break; }
         }
+#if defined(WALK_ABLATE) && WALK_ABLATE == 3      // large-pattern rounds done, small pattern skipped
+        if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = pc - c0; o[1] = pr - r0; }
+        return;
+#endif
         // small pattern, offsets applied swapped (bbme.py:518-521): (0,0),(1,0),(0,1),(-1,0),(0,-1) -> row += o[1], col += o[0]
         {
             int br = pr, bc = pc;
-            const int rrv = clamp_ref(pr + my_sr, maxr), ccv = clamp_ref(pc + my_sc, maxc);
+            const int rrv = clamp_med3(pr + my_sr, maxr), ccv = clamp_med3(pc + my_sc, maxc);
             unsigned kmin;
             PATTERN_MIN(4, 1, rrv, ccv, kmin);
             if ((kmin >> 3) < centre_cost) {
@@ -365,6 +436,32 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
     }
 }
 
+// Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
+// dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
+template <int PNORM>
+__global__ void __launch_bounds__(256) k_walk16(WalkDev d)
+{
+    __shared__ uint32_t win_all[4][WIN_ALLOC];
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nblk = d.nbr * d.nbc;
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b serves pair
+    // (b/8/WPP)*8 + b%8 -- all blocks of a frame pair walk through one XCD's L2
+    const int per = 4 * d.bpw, wpp = (nblk + per - 1) / per;
+    const int pair = ((int)blockIdx.x / 8 / wpp) * 8 + ((int)blockIdx.x & 7);
+    const int base = (((int)blockIdx.x >> 3) % wpp) * per + wave_in_wg;
+    if (pair >= d.pairs) return;                               // wave-uniform
+    if (base >= nblk) return;
+    WalkPre next;
+    walk_prefetch(next, d, pair, base);
+    for (int i = 0; i < d.bpw; ++i) {
+        const int blk = base + 4 * i;
+        if (blk >= nblk) break;
+        const WalkPre now = next;
+        if (i + 1 < d.bpw && blk + 4 < nblk) walk_prefetch(next, d, pair, blk + 4);     // in flight during this block's walk
+        walk_block<PNORM>(d, pair, blk, nblk, win_all[wave_in_wg], now);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // dense 2x2 diamond search, one lane per block
 // ---------------------------------------------------------------------------
@@ -438,11 +535,13 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf; d.status = ctx->status;
     const long long total = (long long)nbr * nbc * job.pairs;
     if (job.bs == 16) {
-        const long long wpp = ((long long)nbr * nbc + 3) / 4;
+        static const int bpw_env = getenv("GME_WALK_BPW") ? atoi(getenv("GME_WALK_BPW")) : 0;
+        d.bpw = bpw_env >= 1 && bpw_env <= 64 ? bpw_env : 8;
+        const long long wpp = ((long long)nbr * nbc + 4 * d.bpw - 1) / (4 * d.bpw);
         const long long groups = (long long)((job.pairs + 7) / 8) * 8 * wpp;
         GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
         const unsigned grid = (unsigned)groups;
-        plan_note(ctx, 0, "k_walk16<%d> grid %u", job.pnorm, (unsigned)grid);
+        plan_note(ctx, 0, "k_walk16<%d> grid %u blocks/wave %d", job.pnorm, (unsigned)grid, d.bpw);
         if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
         else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
