@@ -206,21 +206,22 @@ __device__ __forceinline__ void first_window(const WalkDev& d, int blk, int& wr0
     wc0 = max(0, (clamp_ref(c0, d.W - 17) - (WIN_SPAN - 3) / 2) & ~3);          // never left of the frame, see window_load
 }
 
+template <bool DIA>
 __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int pair, int blk)
 {
     const int lane = threadIdx.x & 63;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)(r0 + (lane & 7) * 2) * d.pitch + c0;
     f.a0 = *(const uint4*)ap; f.a1 = *(const uint4*)(ap + d.pitch);              // 16-byte aligned
-    if (d.procedure == GME_SEARCH_DIAMOND) {
+    if (DIA) {
         int wr0, wc0;
         first_window(d, blk, wr0, wc0);
         window_load(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, wr0, wc0, lane);
     }
 }
 
-// one 16x16 block of one frame pair, walked by one wave
-template <int PNORM>
+// one 16x16 block of one frame pair, walked by one wave (DIA: the diamond search, else three-step or 2-D log)
+template <int PNORM, bool DIA>
 __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, const int blk, const int nblk, uint32_t* win,
                                            const WalkPre& pre)
 {
@@ -277,7 +278,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     bool overrun = false;
     const int cap = 2 * (H + W) + 64;
 
-    if (d.procedure == GME_SEARCH_DIAMOND) {
+    if (DIA) {
         const int maxr = H - 16 - 1, maxc = W - 16 - 1;
         const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };   // LDSP minus its centre
         int pr = r0, pc = c0;
@@ -331,7 +332,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         return;
 #endif
         int it = 0;
-        for (;;) {
+        bool done;
+        do {
             const int rrv = clamp_med3(pr + my_dr, maxr), ccv = clamp_med3(pc + my_dc, maxc);
             unsigned kmin;
             PATTERN_MIN(8, 2, rrv, ccv, kmin);
@@ -344,11 +346,10 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                 bc = clamp_ref(pc + (int)((0x10123432u >> (4 * k)) & 15u) - 2, maxc);
                 centre_cost = kmin >> 3;
             }
-            const bool done = (br == pr && bc == pc);
+            done = (br == pr && bc == pc);
             pr = br; pc = bc;                                  // next centre is already clamped
-            if (done) break;
-            if (++it > cap) { overrun = true; break; }
-        }
+        } while (!done && ++it <= cap);
+        overrun = !done;
 #if defined(WALK_ABLATE) && WALK_ABLATE == 3      // large-pattern rounds done, small pattern skipped
         if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = pc - c0; o[1] = pr - r0; }
         return;
@@ -438,7 +439,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 
 // Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
 // dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
-template <int PNORM>
+template <int PNORM, bool DIA>
 __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
 {
     __shared__ uint32_t win_all[4][WIN_ALLOC];
@@ -452,13 +453,13 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
     if (pair >= d.pairs) return;                               // wave-uniform
     if (base >= nblk) return;
     WalkPre next;
-    walk_prefetch(next, d, pair, base);
+    walk_prefetch<DIA>(next, d, pair, base);
     for (int i = 0; i < d.bpw; ++i) {
         const int blk = base + 4 * i;
         if (blk >= nblk) break;
         const WalkPre now = next;
-        if (i + 1 < d.bpw && blk + 4 < nblk) walk_prefetch(next, d, pair, blk + 4);     // in flight during this block's walk
-        walk_block<PNORM>(d, pair, blk, nblk, win_all[wave_in_wg], now);
+        if (i + 1 < d.bpw && blk + 4 < nblk) walk_prefetch<DIA>(next, d, pair, blk + 4);     // in flight during this block's walk
+        walk_block<PNORM, DIA>(d, pair, blk, nblk, win_all[wave_in_wg], now);
     }
 }
 
@@ -541,9 +542,12 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         const long long groups = (long long)((job.pairs + 7) / 8) * 8 * wpp;
         GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
         const unsigned grid = (unsigned)groups;
-        plan_note(ctx, 0, "k_walk16<%d> grid %u blocks/wave %d", job.pnorm, (unsigned)grid, d.bpw);
-        if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
-        else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
+        plan_note(ctx, 0, "k_walk16<%d,%s> grid %u blocks/wave %d", job.pnorm, job.procedure == GME_SEARCH_DIAMOND ? "diamond" : "steps", (unsigned)grid, d.bpw);
+        const bool dia = job.procedure == GME_SEARCH_DIAMOND;     // its own instance: half the scalar state of the other two
+        if (job.pnorm == 0 && dia) hipLaunchKernelGGL((k_walk16<0, true>), dim3(grid), dim3(256), 0, ctx->stream, d);
+        else if (job.pnorm == 0) hipLaunchKernelGGL((k_walk16<0, false>), dim3(grid), dim3(256), 0, ctx->stream, d);
+        else if (dia) hipLaunchKernelGGL((k_walk16<1, true>), dim3(grid), dim3(256), 0, ctx->stream, d);
+        else hipLaunchKernelGGL((k_walk16<1, false>), dim3(grid), dim3(256), 0, ctx->stream, d);
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
         const unsigned grid = (unsigned)((total + 255) / 256);
         plan_note(ctx, 0, "k_dense2<%d> grid %u", job.pnorm, (unsigned)grid);
