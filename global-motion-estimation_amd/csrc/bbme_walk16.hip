@@ -103,6 +103,16 @@ constexpr int WIN_ALLOC = 43 * WIN_PITCH;      // staging moves 128 sixteen-byte
 
 // Window staging in two halves, so that the loads of a block's first window can be in flight while the
 // wave still walks the block before it: 3 sixteen-byte segments per row, 2 segments per lane.
+// buffer resource over one H x pitch plane plus `slack` bytes (pointer and size wave-uniform)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const uint8_t* plane, int bytes)
+{
+    const uint64_t base = (uint64_t)plane;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)base)),
+        (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 __device__ __forceinline__ void window_load(uint32_t (&v)[2][4], const uint8_t* cur, int pitch, int H, int wr0, int wc0,
                                             int lane)
 {
@@ -114,16 +124,12 @@ __device__ __forceinline__ void window_load(uint32_t (&v)[2][4], const uint8_t* 
     // (no s_waitcnt between them and the walk of the current block).
     // The range is 12 bytes longer than the plane so that a 16-byte segment starting in the last 12 bytes of the
     // last row is not dropped as a whole; every plane has a guard row behind it (plane_alloc, gme_bbme_u8).
-    const uint64_t base = (uint64_t)cur;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)base)),
-        (short)0, __builtin_amdgcn_readfirstlane(H * pitch + 12), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = plane_rsrc(cur, H * pitch + 12);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int seg = lane + 64 * it;
         const int row = seg / 3, s4 = seg - row * 3;
-        const int off = (wr0 + row) * pitch + wc0 + 16 * s4;                 // negative = far out of range as unsigned
+        const int off = __mul24(wr0 + row, pitch) + wc0 + 16 * s4;           // negative = far out of range as unsigned
         const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
     }
@@ -211,8 +217,12 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
 {
     const int lane = threadIdx.x & 63;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
-    const uint8_t* ap = d.prev + (long long)pair * d.plane_stride + (long long)(r0 + (lane & 7) * 2) * d.pitch + c0;
-    f.a0 = *(const uint4*)ap; f.a1 = *(const uint4*)(ap + d.pitch);              // 16-byte aligned
+    // anchors through a buffer resource as well: 32-bit offsets instead of 64-bit pointer arithmetic per lane
+    const __amdgpu_buffer_rsrc_t ra = plane_rsrc(d.prev + (long long)pair * d.plane_stride, d.H * d.pitch);
+    const int aoff = __mul24(r0 + (lane & 7) * 2, d.pitch) + c0;
+    const u32x4_t t0 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff, 0, 0);
+    const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + d.pitch, 0, 0);
+    f.a0 = make_uint4(t0.x, t0.y, t0.z, t0.w); f.a1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
     if (DIA) {
         int wr0, wc0;
         first_window(d, blk, wr0, wc0);
@@ -452,14 +462,19 @@ __global__ void __launch_bounds__(256) k_walk16(WalkDev d)
     const int base = (((int)blockIdx.x >> 3) % wpp) * per + wave_in_wg;
     if (pair >= d.pairs) return;                               // wave-uniform
     if (base >= nblk) return;
-    WalkPre next;
-    walk_prefetch<DIA>(next, d, pair, base);
-    for (int i = 0; i < d.bpw; ++i) {
-        const int blk = base + 4 * i;
-        if (blk >= nblk) break;
-        const WalkPre now = next;
-        if (i + 1 < d.bpw && blk + 4 < nblk) walk_prefetch<DIA>(next, d, pair, blk + 4);     // in flight during this block's walk
-        walk_block<PNORM, DIA>(d, pair, blk, nblk, win_all[wave_in_wg], now);
+    // two prefetch buffers used in turn (the loop is unrolled by two so that no registers are copied around)
+    WalkPre pa, pb;
+    walk_prefetch<DIA>(pa, d, pair, base);
+    for (int i = 0; i < d.bpw; i += 2) {
+        const int blk = base + 4 * i;                               // valid: checked before it was fetched
+        const bool more1 = i + 1 < d.bpw && blk + 4 < nblk;
+        if (more1) walk_prefetch<DIA>(pb, d, pair, blk + 4);         // in flight during this block's walk
+        walk_block<PNORM, DIA>(d, pair, blk, nblk, win_all[wave_in_wg], pa);
+        if (!more1) break;
+        const bool more2 = i + 2 < d.bpw && blk + 8 < nblk;
+        if (more2) walk_prefetch<DIA>(pa, d, pair, blk + 8);
+        walk_block<PNORM, DIA>(d, pair, blk + 4, nblk, win_all[wave_in_wg], pb);
+        if (!more2) break;
     }
 }
 
