@@ -156,15 +156,15 @@ __device__ __forceinline__ void stage_walk_window(uint32_t* lds, const uint8_t* 
 }
 
 template <int PNORM>
-__device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int wr0,
-                                                   int wc0, int rr, int cc, bool valid, int lrow)
+__device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int sbase,
+                                                   int rr, int cc, bool valid, int lrow)
 {
     unsigned part = 0;
     if (valid) {
         // window origin columns are multiples of 4 (wc0 = ... & ~3), so the byte shift is cc & 3 and the dword column
-        // (cc & ~3) - wc0; everything wave-uniform (window origin, LDS base) folds into one scalar: mad24 + and + add3
+        // (cc & ~3) - wc0; everything wave-uniform (window origin: sbase = -wr0 * row bytes - wc0, LDS base) folds
+        // into one scalar: mad24 + and + add3
         const uint32_t sh = (uint32_t)cc & 3u;
-        const int sbase = -wr0 * (4 * WIN_PITCH) - wc0;
         static_assert(4 * WIN_PITCH == 52, "row pitch in bytes is spelled out in the asm below");
         int rowoff;                                              // valid candidates have 0 <= rr < 2^24; asm keeps the compiler
         asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow * (4 * WIN_PITCH)));   // from re-deriving a v_mul_lo_u32
@@ -279,7 +279,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         }                                                                                            \
         int rr_ = 0, cc_ = 0; bool ok_ = false;                                                      \
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (grp == k_) { rr_ = CR[k_]; cc_ = CC[k_]; ok_ = OK[k_]; } \
-        const unsigned c_ = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, wr0, wc0, rr_, cc_, ok_, lrow)  \
+        const unsigned c_ = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, -wr0 * (4 * WIN_PITCH) - wc0, rr_, cc_, ok_, lrow)  \
                                     : group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);     \
         _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
     } while (0)
@@ -290,40 +290,49 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 
     if (DIA) {
         const int maxr = H - 16 - 1, maxc = W - 16 - 1;
-        const int ldr[8] = { 2, 1, 0, -1, -2, -1, 0, 1 }, ldc[8] = { 0, 1, 2, 1, 0, -1, -2, -1 };   // LDSP minus its centre
+        // (pr, pc): origin the pattern offsets are added to; (qr, qc): its clamped position = candidate 0 of the
+        // pattern.  They differ only before the first round, when the block sits in the last block row / column
+        // (r0 = H - 16 = maxr + 1); bbme.py:498-510 then spends one extra round moving onto the clamped position.
         int pr = r0, pc = c0;
+        int qr = clamp_ref(r0, maxr), qc = clamp_ref(c0, maxc);
+        bool raw = (qr != pr) | (qc != pc);
         unsigned centre_cost;
+        // The window holds every pattern (|offset| <= 2, candidates clamped into the frame: within 2 of the clamped
+        // centre) whose clamped centre lies in [cr_lo, cr_lo + 20] x [cc_lo, cc_lo + cc_span]; sbase is the
+        // wave-uniform part of a candidate's LDS byte address.  Two unsigned compares per round instead of clamps.
+        int cr_lo, cc_lo, cc_span, sbase;
+#define WINDOW_RANGES()                                                                               \
+    do {                                                                                             \
+        cr_lo = wr0 + 2; cc_lo = wc0 == 0 ? 0 : wc0 + 2; cc_span = wc0 + WIN_SPAN - 2 - cc_lo;       \
+        sbase = -wr0 * (4 * WIN_PITCH) - wc0;                                                        \
+    } while (0)
+#define RESTAGE_IF_OUTSIDE()                                                                          \
+    do {                                                                                             \
+        if (!((unsigned)(qr - cr_lo) <= (unsigned)(WIN_ROWS - 16 - 4) && (unsigned)(qc - cc_lo) <= (unsigned)cc_span)) { \
+            const int rmin_ = max(qr - 2, 0), rmax_ = min(qr + 2, maxr);                             \
+            const int cmin_ = max(qc - 2, 0), cmax_ = min(qc + 2, maxc);                             \
+            wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                     \
+            wc0 = max(0, (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3);                       \
+            stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
+            WINDOW_RANGES();                                                                         \
+        }                                                                                            \
+    } while (0)
         first_window(d, blk, wr0, wc0);                 // fetched ahead by walk_prefetch
         window_store(win, pre.w, lane);
-        have_win = true;
-        // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns
-        int my_dr = 0, my_dc = 0, my_sr = 0, my_sc = 0;
-        const int sdr[4] = { 0, 1, 0, -1 }, sdc[4] = { 1, 0, -1, 0 };
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (grp == k) { my_dr = ldr[k]; my_dc = ldc[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (grp == k) { my_sr = sdr[k]; my_sc = sdc[k]; }
+        WINDOW_RANGES();
+        // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns, from nibble tables:
+        // LDSP minus its centre (2,0),(1,1),(0,2),(-1,1),(-2,0),(-1,-1),(0,-2),(1,-1) as (row, col); the small
+        // pattern's offsets are applied swapped (bbme.py:518-521): (0,1),(1,0),(0,-1),(-1,0)
+        const int my_dr = (int)((0x32101234u >> (4 * grp)) & 15u) - 2, my_dc = (int)((0x10123432u >> (4 * grp)) & 15u) - 2;
+        const int my_sr = (int)((0x0121u >> (4 * (grp & 3))) & 15u) - 1, my_sc = (int)((0x1012u >> (4 * (grp & 3))) & 15u) - 1;
         // Winner of a pattern without leaving the vector unit: every lane of group k holds candidate k's
         // cost, key = cost << 3 | k (cost < 2^24), minimum over the 8 groups by one DPP rotate inside
         // each 16-lane row, two row broadcasts and one v_readlane.  Only a key whose cost is strictly below the centre's
         // moves the centre (bbme.py:507-510: first strict minimum, the centre is candidate 0); the
-        // winner's offset comes out of nibble tables, so no per-candidate scalar position is needed.
-#define PATTERN_MIN(n, SPAN, RRV, CCV, KMIN)                                                          \
+        // winner's offset comes out of the same nibble tables, so no per-candidate scalar position is needed.
+#define PATTERN_MIN(n, RRV, CCV, KMIN)                                                                \
     do {                                                                                             \
-        /* every candidate is clamp(centre + d), |d| <= SPAN, and the clamp is 1-Lipschitz, so the    \
-           pattern lies within SPAN of the clamped centre: two unsigned range tests decide whether \
-           the window still holds it (conservative: a miss only costs a re-stage) */               \
-        const int prc_ = clamp_ref(pr, maxr), pcc_ = clamp_ref(pc, maxc);                            \
-        if (!(have_win && (unsigned)(prc_ - (SPAN) - wr0) <= (unsigned)(WIN_ROWS - 16 - 2 * (SPAN)) && \
-              (unsigned)(max(pcc_ - (SPAN), 0) - wc0) <= (unsigned)(WIN_SPAN - 2 * (SPAN)))) {       \
-            const int rmin_ = clamp_ref(pr - (SPAN), maxr), rmax_ = clamp_ref(pr + (SPAN), maxr);    \
-            const int cmin_ = clamp_ref(pc - (SPAN), maxc), cmax_ = clamp_ref(pc + (SPAN), maxc);    \
-            wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                     \
-            wc0 = max(0, (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3);                       \
-            stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                                   \
-            have_win = true;                                                                         \
-        }                                                                                            \
-        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, wr0, wc0, RRV, CCV, grp < (n), lrow);  \
+        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, sbase, RRV, CCV, grp < (n), lrow);     \
         unsigned key_ = grp < (n) ? (c_ << 3) | (unsigned)grp : INF32;                               \
         key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x128, 0xF, 0xF, false)); /* row_ror 8 */ \
         /* rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31): lane 63 ends with the minimum */ \
@@ -331,10 +340,9 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x143, 0xC, 0xF, false)); \
         KMIN = (unsigned)__builtin_amdgcn_readlane((int)key_, 63);                                   \
     } while (0)
-        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once
-            const int rr0 = clamp_ref(pr, maxr), cc0 = clamp_ref(pc, maxc);
+        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once; the prefetched window is built around it
             unsigned k0;
-            PATTERN_MIN(1, 0, rr0, cc0, k0);
+            PATTERN_MIN(1, qr, qc, k0);
             centre_cost = k0 >> 3;
         }
 #if defined(WALK_ABLATE) && WALK_ABLATE == 2      // first window staged + centre evaluated
@@ -342,43 +350,47 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         return;
 #endif
         int it = 0;
-        bool done;
+        bool again;
         do {
+            RESTAGE_IF_OUTSIDE();
             const int rrv = clamp_med3(pr + my_dr, maxr), ccv = clamp_med3(pc + my_dc, maxc);
             unsigned kmin;
-            PATTERN_MIN(8, 2, rrv, ccv, kmin);
-            // candidate 0 of the pattern is the clamped centre itself
-            int br = clamp_ref(pr, maxr), bc = clamp_ref(pc, maxc);
-            if ((kmin >> 3) < centre_cost) {
+            PATTERN_MIN(8, rrv, ccv, kmin);
+            // A strictly better candidate moves the centre; its clamped position differs from the centre's (equal
+            // positions have equal costs), so "the centre did not move" (bbme.py:511) is "nothing was better" --
+            // except in the one round that starts from an unclamped origin.
+            const bool better = (kmin >> 3) < centre_cost;
+            if (better) {
                 const unsigned k = kmin & 7u;
-                // ldr + 2 = 4,3,2,1,0,1,2,3 and ldc + 2 = 2,3,4,3,2,1,0,1 as nibbles, k = 0 lowest
-                br = clamp_ref(pr + (int)((0x32101234u >> (4 * k)) & 15u) - 2, maxr);
-                bc = clamp_ref(pc + (int)((0x10123432u >> (4 * k)) & 15u) - 2, maxc);
+                qr = clamp_ref(pr + (int)((0x32101234u >> (4 * k)) & 15u) - 2, maxr);
+                qc = clamp_ref(pc + (int)((0x10123432u >> (4 * k)) & 15u) - 2, maxc);
                 centre_cost = kmin >> 3;
             }
-            done = (br == pr && bc == pc);
-            pr = br; pc = bc;                                  // next centre is already clamped
-        } while (!done && ++it <= cap);
-        overrun = !done;
+            again = better | raw;
+            raw = false;
+            pr = qr; pc = qc;                                  // from here on the origin is a clamped position
+        } while (again && ++it <= cap);
+        overrun = again;
 #if defined(WALK_ABLATE) && WALK_ABLATE == 3      // large-pattern rounds done, small pattern skipped
         if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = pc - c0; o[1] = pr - r0; }
         return;
 #endif
-        // small pattern, offsets applied swapped (bbme.py:518-521): (0,0),(1,0),(0,1),(-1,0),(0,-1) -> row += o[1], col += o[0]
-        {
+        {   // small pattern around the final centre
+            RESTAGE_IF_OUTSIDE();
             int br = pr, bc = pc;
             const int rrv = clamp_med3(pr + my_sr, maxr), ccv = clamp_med3(pc + my_sc, maxc);
             unsigned kmin;
-            PATTERN_MIN(4, 1, rrv, ccv, kmin);
+            PATTERN_MIN(4, rrv, ccv, kmin);
             if ((kmin >> 3) < centre_cost) {
                 const unsigned k = kmin & 3u;
-                // sdr + 1 = 1,2,1,0 and sdc + 1 = 2,1,0,1 as nibbles
                 br = clamp_ref(pr + (int)((0x0121u >> (4 * k)) & 15u) - 1, maxr);
                 bc = clamp_ref(pc + (int)((0x1012u >> (4 * k)) & 15u) - 1, maxc);
             }
             out1 = br - r0; out0 = bc - c0;
         }
 #undef PATTERN_MIN
+#undef RESTAGE_IF_OUTSIDE
+#undef WINDOW_RANGES
     } else if (d.procedure == GME_SEARCH_THREESTEP) {
         const int n = 2 * d.sw + 16;
         const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };
@@ -450,7 +462,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 // Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
 // dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
 template <int PNORM, bool DIA>
-__global__ void __launch_bounds__(256) k_walk16(WalkDev d)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_walk16(WalkDev d)
 {
     __shared__ uint32_t win_all[4][WIN_ALLOC];
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
