@@ -1,15 +1,20 @@
 // Walk searches (diamond, three-step, 2-D log) specialised for the two geometries the
 // global-motion pipeline runs all the time (motion.py:27-29,224-229):
 //
-//   k_walk16<PNORM>   bs = 16: one wavefront per macroblock.  The wave is cut into 8 groups
+//   k_walk16<PNORM, DIA>  bs = 16: one wavefront per macroblock, 8 blocks per wave one after the other (the
+//                     next block's anchors and first window are fetched while the current one is walked, two
+//                     register sets used in turn).  The wave is cut into 8 groups
 //                     of 8 lanes; a group evaluates one candidate per round, each lane owning
 //                     two 16-byte rows of the block (ten dwords of the per-wave LDS window of
 //                     `cur`, 8 v_alignbyte_b32, 8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8
 //                     anchor dwords kept in VGPRs), followed by a 3-step DPP reduction inside
 //                     the group.  Up to 8 candidates cost one round; the centre of a pattern is
-//                     the previous winner, whose cost is carried instead of recomputed.  Diamond
-//                     rounds pick the winner in the vector unit (PATTERN_MIN); three-step and
-//                     2-D log keep wave-uniform candidate arrays (EVAL8).
+//                     the previous winner, whose cost is carried instead of recomputed.  The window is
+//                     staged branch-free through a buffer resource (out-of-plane reads return 0).
+//                     DIA = true is the diamond search on its own (the GME levels 1-2): rounds pick
+//                     the winner in the vector unit (PATTERN_MIN), 41 vector + ~35 scalar instructions
+//                     per round of 8 candidates under MSE.  DIA = false: three-step and
+//                     2-D log, which keep wave-uniform candidate arrays (EVAL8).
 //   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
 //                     coarsest pyramid level, 5400 blocks per 720x480 pair).
 //
