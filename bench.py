@@ -336,7 +336,10 @@ def main():
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
     # not matter and concurrent persistent kernels only contend: 17.5 k pairs/s on one stream, 15 k on three)
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "4"))     # 1/2/3/4/6 streams: 396/381/412/424/355 k pairs/s (gme720)
+    # At 720x480 one stream is the fastest and the steadiest now that the level searches are short
+    # (1/2/3/4 streams: 497/452/499/385-407 k pairs/s on one box, 296 k on another with 4); at 1080p the kernels are
+    # long enough for three ranges to pay (seq1080: 99.8 k on one stream, 102.6 k on four).
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 or H * W < 1000000 else "3"))
     shard = seq = None
     if proc == -3:
         import sequence
