@@ -160,20 +160,20 @@ __device__ __forceinline__ void stage_walk_window(uint32_t* lds, const uint8_t* 
     window_store(lds, v, lane);
 }
 
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+
+__device__ __forceinline__ int lds_address(const uint32_t* p)       // byte address of a __shared__ object inside the LDS
+{
+    return (int)(uint32_t)(uintptr_t)(lds_u32*)p;
+}
+
+// cost of the candidate whose two rows for this lane start at LDS byte address `addr` (shift sh inside the dword)
 template <int PNORM>
-__device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int sbase,
-                                                   int rr, int cc, bool valid, int lrow)
+__device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsigned aa, int addr, uint32_t sh, bool valid)
 {
     unsigned part = 0;
     if (valid) {
-        // window origin columns are multiples of 4 (wc0 = ... & ~3), so the byte shift is cc & 3 and the dword column
-        // (cc & ~3) - wc0; everything wave-uniform (window origin: sbase = -wr0 * row bytes - wc0, LDS base) folds
-        // into one scalar: mad24 + and + add3
-        const uint32_t sh = (uint32_t)cc & 3u;
-        static_assert(4 * WIN_PITCH == 52, "row pitch in bytes is spelled out in the asm below");
-        int rowoff;                                              // valid candidates have 0 <= rr < 2^24; asm keeps the compiler
-        asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow * (4 * WIN_PITCH)));   // from re-deriving a v_mul_lo_u32
-        const uint32_t* p = (const uint32_t*)((const char*)lds + (rowoff + ((cc & ~3) + sbase)));
+        lds_u32* p = (lds_u32*)(uint32_t)addr;
         uint32_t l0[5], l1[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[WIN_PITCH + j]; }
@@ -202,11 +202,31 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
     return valid ? part : INF32;
 }
 
+static_assert(4 * WIN_PITCH == 52, "row pitch in bytes is spelled out in the asm below");
+
+// byte offset of candidate (rr, cc)'s rows lrow, lrow + 1 in the window.  Window origin columns are multiples of 4
+// (wc0 = ... & ~3), so the byte shift is cc & 3 and the dword column (cc & ~3) - wc0; everything wave-uniform
+// (window origin: sbase = -wr0 * row bytes - wc0) folds into one scalar: mad24 + and + add
+__device__ __forceinline__ int window_offset(int sbase, int rr, int cc, int lrow52)
+{
+    int rowoff;                                              // valid candidates have 0 <= rr < 2^24; asm keeps the compiler
+    asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow52));   // from re-deriving a v_mul_lo_u32
+    return rowoff + ((cc & ~3) + sbase);
+}
+
+template <int PNORM>
+__device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int sbase,
+                                                   int rr, int cc, bool valid, int lrow)
+{
+    return group_eval_at<PNORM>(a, aa, window_offset(sbase + lds_address(lds), rr, cc, lrow * (4 * WIN_PITCH)), (uint32_t)cc & 3u, valid);
+}
+
 // What a wave fetches ahead for a block: its 2 anchor rows per lane and, for the diamond search (whose first
 // window position depends on the block alone), the lane's share of that window.
 struct WalkPre {
     uint4 a0, a1;
     uint32_t w[2][4];
+    uint32_t mine;          // diamond: anchor dword (row lane / 4, dword lane % 4) for the all-lanes cost of the first centre
 };
 
 // first window of a diamond walk: the one PATTERN_MIN would stage around the clamped block origin
@@ -229,6 +249,7 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
     const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + d.pitch, 0, 0);
     f.a0 = make_uint4(t0.x, t0.y, t0.z, t0.w); f.a1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
     if (DIA) {
+        f.mine = __builtin_amdgcn_raw_buffer_load_b32(ra, __mul24(r0 + (lane >> 2), d.pitch) + c0 + 4 * (lane & 3), 0, 0);
         int wr0, wc0;
         first_window(d, blk, wr0, wc0);
         window_load(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, wr0, wc0, lane);
@@ -304,12 +325,12 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         unsigned centre_cost;
         // The window holds every pattern (|offset| <= 2, candidates clamped into the frame: within 2 of the clamped
         // centre) whose clamped centre lies in [cr_lo, cr_lo + 20] x [cc_lo, cc_lo + cc_span]; sbase is the
-        // wave-uniform part of a candidate's LDS byte address.  Two unsigned compares per round instead of clamps.
+        // wave-uniform part of a candidate's LDS byte address (window base included).  Two unsigned compares per round instead of clamps.
         int cr_lo, cc_lo, cc_span, sbase;
 #define WINDOW_RANGES()                                                                               \
     do {                                                                                             \
         cr_lo = wr0 + 2; cc_lo = wc0 == 0 ? 0 : wc0 + 2; cc_span = wc0 + WIN_SPAN - 2 - cc_lo;       \
-        sbase = -wr0 * (4 * WIN_PITCH) - wc0;                                                        \
+        sbase = lds_address(win) - wr0 * (4 * WIN_PITCH) - wc0;                                      \
     } while (0)
 #define RESTAGE_IF_OUTSIDE()                                                                          \
     do {                                                                                             \
@@ -329,15 +350,15 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         // LDSP minus its centre (2,0),(1,1),(0,2),(-1,1),(-2,0),(-1,-1),(0,-2),(1,-1) as (row, col); the small
         // pattern's offsets are applied swapped (bbme.py:518-521): (0,1),(1,0),(0,-1),(-1,0)
         const int my_dr = (int)((0x32101234u >> (4 * grp)) & 15u) - 2, my_dc = (int)((0x10123432u >> (4 * grp)) & 15u) - 2;
-        const int my_sr = (int)((0x0121u >> (4 * (grp & 3))) & 15u) - 1, my_sc = (int)((0x1012u >> (4 * (grp & 3))) & 15u) - 1;
+        const int lrow52 = lrow * (4 * WIN_PITCH);
         // Winner of a pattern without leaving the vector unit: every lane of group k holds candidate k's
         // cost, key = cost << 3 | k (cost < 2^24), minimum over the 8 groups by one DPP rotate inside
         // each 16-lane row, two row broadcasts and one v_readlane.  Only a key whose cost is strictly below the centre's
         // moves the centre (bbme.py:507-510: first strict minimum, the centre is candidate 0); the
         // winner's offset comes out of the same nibble tables, so no per-candidate scalar position is needed.
-#define PATTERN_MIN(n, RRV, CCV, KMIN)                                                                \
+#define PATTERN_MIN(n, OFF, SH, KMIN)                                                                  \
     do {                                                                                             \
-        const unsigned c_ = group_eval_lds<PNORM>(a, aa, win, sbase, RRV, CCV, grp < (n), lrow);     \
+        const unsigned c_ = group_eval_at<PNORM>(a, aa, OFF, SH, grp < (n));                        \
         unsigned key_ = grp < (n) ? (c_ << 3) | (unsigned)grp : INF32;                               \
         key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x128, 0xF, 0xF, false)); /* row_ror 8 */ \
         /* rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31): lane 63 ends with the minimum */ \
@@ -345,10 +366,26 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x143, 0xC, 0xF, false)); \
         KMIN = (unsigned)__builtin_amdgcn_readlane((int)key_, 63);                                   \
     } while (0)
-        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once; the prefetched window is built around it
-            unsigned k0;
-            PATTERN_MIN(1, qr, qc, k0);
-            centre_cost = k0 >> 3;
+        {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once, by all 64 lanes together: lane l takes
+            // dword l % 4 of block row l / 4 (two window dwords, one v_alignbyte with a scalar shift, one v_sad_u8 or
+            // two v_dot4), then 7 DPP adds leave the cost in lane 63 -- a third of the instructions of a
+            // pattern round that would keep 7 of the 8 groups idle.  The prefetched window is built around it.
+            lds_u32* p = (lds_u32*)(uint32_t)((lane >> 2) * (4 * WIN_PITCH) + 4 * (lane & 3) +
+                                              (qr * (4 * WIN_PITCH) + (qc & ~3) + sbase));
+            const uint32_t b = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)qc & 3u);
+            unsigned part;
+            if (PNORM == 0) {
+                part = __builtin_amdgcn_sad_u8(pre.mine, b, 0u);
+            } else {
+                const unsigned bb = __builtin_amdgcn_udot4(b, b, __builtin_amdgcn_udot4(pre.mine, pre.mine, 0u, false), false);
+                const unsigned ab = __builtin_amdgcn_udot4(pre.mine, b, 0u, false);
+                asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
+            }
+            part = group8_sum(part);
+            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x128, 0xF, 0xF, false);     // row_ror 8: 16-lane rows
+            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x142, 0xA, 0xF, false);     // row_bcast15 into rows 1, 3
+            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x143, 0xC, 0xF, false);     // row_bcast31 into rows 2, 3
+            centre_cost = (unsigned)__builtin_amdgcn_readlane((int)part, 63);
         }
 #if defined(WALK_ABLATE) && WALK_ABLATE == 2      // first window staged + centre evaluated
         if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)centre_cost >> 30; o[1] = 0; }
@@ -358,9 +395,11 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         bool again;
         do {
             RESTAGE_IF_OUTSIDE();
-            const int rrv = clamp_med3(pr + my_dr, maxr), ccv = clamp_med3(pc + my_dc, maxc);
             unsigned kmin;
-            PATTERN_MIN(8, rrv, ccv, kmin);
+            {
+                const int rrv = clamp_med3(pr + my_dr, maxr), ccv = clamp_med3(pc + my_dc, maxc);
+                PATTERN_MIN(8, window_offset(sbase, rrv, ccv, lrow52), (uint32_t)ccv & 3u, kmin);
+            }
             // A strictly better candidate moves the centre; its clamped position differs from the centre's (equal
             // positions have equal costs), so "the centre did not move" (bbme.py:511) is "nothing was better" --
             // except in the one round that starts from an unclamped origin.
@@ -383,9 +422,14 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         {   // small pattern around the final centre
             RESTAGE_IF_OUTSIDE();
             int br = pr, bc = pc;
+            // offsets worked out here, once per block, rather than kept in two registers through the rounds (the
+            // volatile asm pins the computation to this place: 64 VGPRs are what 8 waves per SIMD allow)
+            int g4 = 4 * (grp & 3);
+            asm volatile("" : "+v"(g4));
+            const int my_sr = (int)((0x0121u >> g4) & 15u) - 1, my_sc = (int)((0x1012u >> g4) & 15u) - 1;
             const int rrv = clamp_med3(pr + my_sr, maxr), ccv = clamp_med3(pc + my_sc, maxc);
             unsigned kmin;
-            PATTERN_MIN(4, rrv, ccv, kmin);
+            PATTERN_MIN(4, window_offset(sbase, rrv, ccv, lrow52), (uint32_t)ccv & 3u, kmin);
             if ((kmin >> 3) < centre_cost) {
                 const unsigned k = kmin & 3u;
                 br = clamp_ref(pr + (int)((0x0121u >> (4 * k)) & 15u) - 1, maxr);
