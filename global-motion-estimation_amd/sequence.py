@@ -72,12 +72,19 @@ def comm_exchange_id(make_id, rank, world, timeout_s=180.0):
     import os
     import time
     path = _id_file()
-    if rank == 0:
-        blob = make_id()
+    def publish(blob):
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
             f.write(blob)
         os.replace(tmp, path)                    # atomic: readers see nothing or everything
+
+    if rank == 0:
+        try:
+            blob = make_id()
+        except Exception:
+            publish(b"FAILED")                   # the others stop waiting at once and take the same fallback
+            raise
+        publish(blob)
         return blob
     t0 = time.time()
     while True:
@@ -86,6 +93,8 @@ def comm_exchange_id(make_id, rank, world, timeout_s=180.0):
                 blob = f.read()
             if len(blob) == 128:
                 return blob
+            if blob == b"FAILED":
+                raise RuntimeError("rank 0 could not create an RCCL id")
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout_s:

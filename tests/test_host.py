@@ -238,6 +238,19 @@ def test_rccl_id_rendezvous_and_padding(tmp_path):
     path = "/tmp/gme_rccl_29777_%d.id" % os.getpid()
     assert os.path.exists(path)
     os.unlink(path)
+    # rank 0 cannot make an id: it says so through the same file and the others give up at once (no 3-minute wait)
+    os.environ["GME_COMM_ID_FILE"] = str(tmp_path / "failed.id")
+    try:
+        def broken():
+            raise OSError("no librccl")
+        with pytest.raises(OSError):
+            sequence.comm_exchange_id(broken, 0, 2)
+        t0 = time.time()
+        with pytest.raises(RuntimeError):
+            sequence.comm_exchange_id(broken, 1, 2, timeout_s=60)
+        assert time.time() - t0 < 5
+    finally:
+        del os.environ["GME_COMM_ID_FILE"]
     assert sequence.pad_and_trim(7, 2) == (4, [(0, 3), (3, 7)])
     assert sequence.pad_and_trim(1999, 8)[0] == 250
     assert sequence.pad_and_trim(0, 4) == (1, [(0, 0)] * 4)
