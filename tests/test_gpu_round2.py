@@ -116,6 +116,49 @@ def test_redo_path_small_batches_and_window_sizes(native, monkeypatch):
             seq.close()
 
 
+@pytest.mark.parametrize("proc", [1, 2, 3])
+def test_walk16_random_shapes(native, proc):
+    """k_walk16 (8 blocks per wave, prefetched through buffer resources) on shapes its grid does not divide evenly:
+    frames barely larger than a block, last block rows / columns that start on max + 1, windows that touch all four
+    frame edges, fields of 1 .. 33 blocks per workgroup; pan, noise, flat and half-noise content, both norms,
+    frame distances 1-3 -- every pair against the C oracle, bit-exact (tools/soak.py ... walk runs the same for minutes)."""
+    co = c_oracle()
+    rng = np.random.default_rng(100 + proc)
+    ctx = native.default_context()
+    shapes = [(17, 17), (20, 305), (32, 32), (33, 47), (48, 64), (64, 96), (100, 130), (144, 176), (219, 339), (16 * 9, 16 * 11 + 5)]
+    checked = 0
+    for H, W in shapes:
+        for kind in ("pan", "noise", "flat", "mixed"):
+            n = int(rng.integers(3, 9))
+            if kind == "pan":
+                base = rng.integers(0, 256, (H + 80, W + 80), dtype=np.uint8)
+                frames = np.stack([base[40 + 2 * (t % 7):40 + 2 * (t % 7) + H, 40 - 3 * (t % 5):40 - 3 * (t % 5) + W] for t in range(n)])
+            elif kind == "noise":
+                frames = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+            elif kind == "flat":
+                frames = np.full((n, H, W), 77, np.uint8)
+            else:
+                base = rng.integers(0, 256, (H + 80, W + 80), dtype=np.uint8)
+                frames = np.stack([base[40 + (t % 5):40 + (t % 5) + H, 40 - 2 * (t % 6):40 - 2 * (t % 6) + W] for t in range(n)]).copy()
+                frames[:, :, :W // 2] = rng.integers(0, 256, (n, H, W // 2), dtype=np.uint8)
+            frames = np.ascontiguousarray(frames)
+            seq = native.Sequence.from_frames(ctx, frames)
+            try:
+                fd = int(rng.integers(1, min(3, n - 1) + 1))
+                sw = int(rng.choice([4, 8, 16, 32]))
+                for pn in (0, 1):
+                    seq.bbme(fd, 16, sw, proc, pn)
+                    mv = seq.read_mv()
+                    assert "k_walk16" in ctx.last_bbme_info()["plan"]
+                    for p in range(n - fd):
+                        want = co.bbme(frames[p], frames[p + fd], 16, sw, proc, pn)
+                        assert np.array_equal(mv[p], want), (H, W, kind, fd, sw, proc, pn, p)
+                        checked += 1
+            finally:
+                seq.close()
+    assert checked >= 200
+
+
 @pytest.mark.parametrize("pnorm", [0, 1])
 def test_benched_instance_1080p_every_pair(native, pnorm):
     """BASELINE configs[3] BBME as benched: 1920x1080, sw = 32, 9 pairs -> persistent k_exh_sea16p<5,.>
