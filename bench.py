@@ -336,20 +336,21 @@ def main():
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
     # not matter and concurrent persistent kernels only contend: 17.5 k pairs/s on one stream, 15 k on three)
-    # At 720x480 one stream is the fastest and the steadiest now that the level searches are short
-    # (1/2/3/4 streams: 497/452/499/385-407 k pairs/s on one box, 296 k on another with 4); at 1080p the kernels are
-    # long enough for three ranges to pay (seq1080: 99.8 k on one stream, 102.6 k on four).
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 or H * W < 1000000 else "3"))
+    # The ranges are driven by ONE host thread through the split-phase calls (ShardedSequence(interleave=True)):
+    # gme720 1 stream 499-513 k pairs/s; 2 / 3 / 4 interleaved streams 582 / 588 / 596 k; with a host thread per
+    # stream (GME_BENCH_INTERLEAVE=0) 2 / 3 / 4 streams gave 452-471 / 499 / 385-407 k on the same boxes.
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "3"))
+    interleave = os.environ.get("GME_BENCH_INTERLEAVE", "1") == "1"      # one host thread over all streams (split-phase calls)
     shard = seq = None
     if proc == -3:
         import sequence
         n_frames = int(os.environ.get("GME_BENCH_FRAMES", "2000"))
-        shard = sequence.ShardedSequence(H, W, n_frames, 1, rank=rank, world=world, ctx=ctx, streams=streams)
+        shard = sequence.ShardedSequence(H, W, n_frames, 1, rank=rank, world=world, ctx=ctx, streams=streams, interleave=interleave)
         shard.synth(seed)                          # each rank generates its own slice (pairs + 1 halo frame)
         B = shard.n_pairs                          # pairs of THIS rank; the step covers the whole sequence
     elif gme:
         import sequence
-        shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams)
+        shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams, interleave=interleave)
         shard.synth(seed, rank * B)                # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
     elif args.content == "synthetic":
         seq = native.Sequence(ctx, B + 1, H, W)

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "gme_seq_gme_read_stage": (_i, [_vp, _i, _i, _c_i32p, _c_i16p, _c_u8p, _c_i64p]),
     "gme_seq_compensate": (_i, [_vp, _i, _i, _c_f64p, _c_i64p]),
     "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
+    "gme_seq_set_split_phase": (_i, [_vp, _i]),
+    "gme_seq_wait": (_i, [_vp]),
 }
 
 _lib = None
@@ -387,10 +389,33 @@ class Sequence:
         return out
 
     # ---- GME stages
+    # -- split-phase calls (gme_seq_set_split_phase): gme_begin / gme_fit / compensate queue their work and hand back
+    #    page-locked arrays that are filled once wait() returns; one host thread can then drive several sequences
+    def set_split_phase(self, on=True):
+        _check(self.lib.gme_seq_set_split_phase(self.handle, int(bool(on))), self.lib)
+        self._split = bool(on)
+        if not on:
+            self._pin = {}
+
+    def wait(self):
+        _check(self.lib.gme_seq_wait(self.handle), self.lib)
+
+    def _buffer(self, name, shape, dtype):
+        """Result / argument array of a staged call: ordinary memory, or (split-phase) one page-locked block per
+        name and shape kept with the sequence -- the copy engine writes it while the caller is elsewhere."""
+        if not getattr(self, "_split", False):
+            return np.empty(shape, dtype=dtype)
+        pin = self.__dict__.setdefault("_pin", {})
+        a = pin.get(name)
+        if a is None or a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
+            a = pinned_empty(shape, dtype) if int(np.prod(shape)) else np.empty(shape, dtype=dtype)
+            pin[name] = a
+        return a
+
     def gme_begin(self, frame_distance, bbme_block_size, procedure=3, search_window=2):
         pairs = self.N - frame_distance
         bbme_block_size = _block_size(bbme_block_size)
-        p0 = np.empty((max(pairs, 0), 6), dtype=np.float32)
+        p0 = self._buffer("p0", (max(pairs, 0), 6), np.float32)
         _check(self.lib.gme_seq_gme_begin(self.handle, frame_distance, bbme_block_size, procedure, search_window,
                                           _p(p0, _c_f32p)), self.lib)
         self._gme = (frame_distance, bbme_block_size, pairs)
@@ -400,8 +425,9 @@ class Sequence:
         """-> sums float64[P, 15] = F (9) | Sx (3) | Sy (3).  level -1 fits the field of the
         last bbme() call against the full-resolution frame size."""
         pairs = self._gme[2] if level >= 0 else self._mv_shape[0]
-        p = np.ascontiguousarray(np.asarray(params_in, dtype=np.float64).reshape(pairs, 6))
-        sums = np.empty((pairs, 15), dtype=np.float64)
+        p = self._buffer("fit_in%d" % level, (pairs, 6), np.float64)
+        p[...] = np.asarray(params_in, dtype=np.float64).reshape(pairs, 6)
+        sums = self._buffer("sums%d" % level, (pairs, 15), np.float64)
         _check(self.lib.gme_seq_gme_fit(self.handle, level, _p(p, _c_f64p), float(outlier_fraction), _p(sums, _c_f64p)),
                self.lib)
         return sums
@@ -429,8 +455,9 @@ class Sequence:
     def compensate(self, frame_distance, block_size, params):
         pairs = self.N - frame_distance
         block_size = _block_size(block_size)
-        p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(pairs, 6))
-        sse = np.empty(pairs, dtype=np.int64)
+        p = self._buffer("comp_in", (pairs, 6), np.float64)
+        p[...] = np.asarray(params, dtype=np.float64).reshape(pairs, 6)
+        sse = self._buffer("sse", (pairs,), np.int64)
         _check(self.lib.gme_seq_compensate(self.handle, frame_distance, block_size, _p(p, _c_f64p), _p(sse, _c_i64p)),
                self.lib)
         return sse

@@ -427,7 +427,31 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     if (s->sse) hipFree(s->sse);
     if (s->comp_params) hipFree(s->comp_params);
     if (s->synth_canvas) hipFree(s->synth_canvas);
+    if (s->ready) hipEventDestroy(s->ready);
     delete s;
+}
+
+// Split-phase calls: with the switch on, gme_seq_gme_begin / gme_seq_gme_fit / gme_seq_compensate queue their work
+// (including the copy of their result into the caller's buffer, which should be page-locked: gme_host_alloc) and
+// return; gme_seq_wait blocks until the result of the LAST such call has arrived -- not until the stream is idle, so
+// the searches queued behind the copy keep running, and one host thread can drive several sequences on several
+// streams, solving one's 3x3 systems while the others' kernels run.
+extern "C" int gme_seq_set_split_phase(gme_seq* s, int on)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    GME_ENTER(s->ctx);
+    if (on && !s->ready) GME_HIP_TRY(hipEventCreateWithFlags(&s->ready, hipEventDisableTiming));
+    s->split_phase = on != 0;
+    return GME_OK;
+}
+
+extern "C" int gme_seq_wait(gme_seq* s)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    GME_ENTER(s->ctx);
+    GME_REQUIRE(s->ready != nullptr, GME_ERR_STATE, "gme_seq_wait without gme_seq_set_split_phase");
+    GME_HIP_TRY(hipEventSynchronize(s->ready));
+    return GME_OK;
 }
 
 // new frame data ends a staged GME run: searches gme_seq_gme_begin deferred must not see other frames
@@ -895,7 +919,8 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
     if (params0_out) {
         GME_HIP_TRY(hipMemcpyAsync(params0_out, s->params0, (size_t)pairs * 6 * sizeof(float), hipMemcpyDeviceToHost,
                                    ctx->stream));
-        rc = ctx_finish(ctx);
+        if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
+        else rc = ctx_finish(ctx);
         if (rc) return rc;
         return gme_level_bbme(s, 1);                       // runs while the caller projects the parameters
     }
@@ -967,7 +992,8 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
                           f->thr, f->sums, f->list);
     if (rc) return rc;
     GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    rc = ctx_finish(ctx);
+    if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
+    else rc = ctx_finish(ctx);
     if (rc) return rc;
     if (level == 1) return gme_level_bbme(s, 2);           // searched while the caller solves level 1
     return GME_OK;
@@ -1031,6 +1057,7 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
     if (rc) return rc;
     if (sse_out) {
         GME_HIP_TRY(hipMemcpyAsync(sse_out, s->sse, (size_t)pairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        if (s->split_phase) { GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream)); return GME_OK; }
         return ctx_finish(ctx);
     }
     return GME_OK;

@@ -102,6 +102,8 @@ struct gme_seq {
     int gme_fd = 0, gme_bs = 0, gme_pairs = 0;
     int gme_procedure = 0, gme_sw = 0;
     bool bbme_pending[3] = { false, false, false };   // level searches gme_seq_gme_begin deferred (see there)
+    bool split_phase = false;     // gme_seq_set_split_phase: begin / fit / compensate return once their work is queued
+    hipEvent_t ready = nullptr;   // recorded behind the last result copy of such a call; gme_seq_wait waits on it
     FitLevelBuf fit[3];           // fit[0].gt = dense field
     FitLevelBuf fit_mv;           // stage buffers for fitting `mv` directly (gt not owned)
     int fit_mv_pairs = 0;

@@ -172,10 +172,16 @@ class ShardedSequence:
     staged estimate (motion.estimate_sequence) has the host solve 3x3 systems between device
     stages; with several streams one range's solves and launch latencies are covered by the
     other ranges' kernels.  Results do not depend on ``streams``.
+
+    ``interleave=True`` drives the ranges from ONE host thread instead, through the split-phase calls
+    of the C ABI (gme_seq_set_split_phase / gme_seq_wait): stage s of every range is queued, then each
+    range's result is awaited and solved in turn while the other ranges' kernels run.  No host threads
+    contend for the interpreter or the BLAS; estimate_and_compensate() is the call that uses it.
     """
 
-    def __init__(self, height, width, n_frames, frame_distance=1, rank=0, world=1, ctx=None, streams=1):
+    def __init__(self, height, width, n_frames, frame_distance=1, rank=0, world=1, ctx=None, streams=1, interleave=False):
         self.ctx = ctx or _native.default_context()
+        self.interleave = bool(interleave)
         self.H, self.W, self.fd = int(height), int(width), int(frame_distance)
         self.n_frames_total = int(n_frames)
         self.n_pairs_total = max(0, self.n_frames_total - self.fd)
@@ -301,12 +307,48 @@ class ShardedSequence:
         if not self.lanes:
             return np.zeros((0, 6)), np.zeros(0)
 
+        if self.interleave and len(self.lanes) > 1:
+            return self._interleaved(procedure, search_window, exact_psnr)
+
         def run(lane):
             n = lane.hi - lane.lo
             p = motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:n]
             return p, lane.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE), p)[:n]
         parts = self._each(run)
         return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]), exact_psnr)
+
+    def _interleaved(self, procedure, search_window, exact_psnr):
+        """estimate_and_compensate() for several ranges from one host thread: every stage is queued on all streams
+        before the first result is awaited, so range k's projection and 3x3 solves (motion.py:191-207,262-282, the
+        same arithmetic as motion.estimate_sequence) run while the other ranges' searches do."""
+        frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
+        bs = int(motion.BBME_BLOCK_SIZE)
+        lanes = self.lanes
+        for lane in lanes:
+            if not getattr(lane.seq, "_split", False):
+                lane.seq.set_split_phase(True)
+        pending = [lane.seq.gme_begin(self.fd, bs, procedure, search_window) for lane in lanes]
+        params = [None] * len(lanes)
+        for level in (1, 2):
+            for k, lane in enumerate(lanes):
+                lane.seq.wait()
+                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
+                p = np.array(pending[k]) if level == 1 else motion._solve_batch(pending[k])
+                p[:, 0] = p[:, 0] * 2
+                p[:, 3] = p[:, 3] * 2
+                pending[k] = lane.seq.gme_fit(level, p.astype(np.float64), frac)
+        sse = [None] * len(lanes)
+        for k, lane in enumerate(lanes):
+            lane.seq.wait()
+            params[k] = motion._solve_batch(pending[k])
+            sse[k] = lane.seq.compensate(self.fd, bs, params[k])
+        out_sse = []
+        for k, lane in enumerate(lanes):
+            lane.seq.wait()
+            out_sse.append(np.array(sse[k][:lane.hi - lane.lo]))
+            lane.ctx.sync()                       # drains the stream and reports a walk that overran its guard
+        return (np.concatenate([p[:lane.hi - lane.lo] for p, lane in zip(params, lanes)], axis=0),
+                self._psnr(np.concatenate(out_sse), exact_psnr))
 
     def read_compensated(self, pair):
         lane, k = self._lane_of(pair)

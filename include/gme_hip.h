@@ -169,6 +169,15 @@ GME_API int gme_seq_compensate(gme_seq *seq, int frame_distance, int block_size,
                        int64_t *sse_out);
 GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
 
+/* Split-phase form of the three calls above (no counterpart in the reference, whose stages are plain function calls,
+ * motion.py:109-136; this is how ONE host thread keeps several streams busy).  With the switch on,
+ * gme_seq_gme_begin / gme_seq_gme_fit / gme_seq_compensate return as soon as their work is queued; their output
+ * buffer (page-locked: gme_host_alloc) is valid after gme_seq_wait, which waits for the result of the last such call
+ * only -- the level search queued behind it keeps running.  gme_sync still drains the stream and reports walk
+ * overruns. */
+GME_API int gme_seq_set_split_phase(gme_seq *seq, int on);
+GME_API int gme_seq_wait(gme_seq *seq);
+
 /* ---------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, contiguous pair ranges per rank (results.py:41-50 carries no state
  * between pairs), and ONE exchange: the all-gather of the per-pair parameter rows over RCCL / xGMI on

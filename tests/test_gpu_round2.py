@@ -231,6 +231,43 @@ def test_sharded_sequence_1080p_shard_vs_oracle(native):
     assert sum(len(g[1]) for g in got) == n - 1
 
 
+def test_interleaved_streams_equal_blocking_calls(native):
+    """Split-phase calls (gme_seq_set_split_phase / gme_seq_wait): three pair ranges driven by ONE host thread give
+    bit for bit the parameters, PSNR and compensated frames of the blocking single-stream path -- twice in a row on
+    the same buffers, with ranges of unequal length -- and the C-oracle chain agrees on sampled pairs."""
+    import sequence
+    import synth
+    n, H, W = 47, 240, 352
+    one = sequence.ShardedSequence(H, W, n, 1, streams=1)
+    one.synth(77)
+    want_p, want_psnr = one.estimate_and_compensate()
+    want_c = [one.read_compensated(k) for k in (0, 17, n - 2)]
+    one.close()
+    il = sequence.ShardedSequence(H, W, n, 1, streams=3, interleave=True)
+    il.synth(77)
+    for _ in range(2):
+        got_p, got_psnr = il.estimate_and_compensate()
+        assert np.array_equal(got_p, want_p) and np.array_equal(got_psnr, want_psnr)
+        for k, c in zip((0, 17, n - 2), want_c):
+            assert np.array_equal(il.read_compensated(k), c), k
+    # the plain calls still block and work on a sequence whose split-phase switch is off again
+    lane = il.lanes[0]
+    lane.seq.set_split_phase(False)
+    p = __import__("motion").estimate_sequence(lane.seq, 1)
+    assert np.array_equal(p[:lane.hi - lane.lo], want_p[lane.lo:lane.hi])
+    il.close()
+    frames = synth.sequence(77, 0, n, H, W)
+    for p in (0, 23, n - 2):
+        wp, _, wc, wpsnr = oracle_results_flow(frames[p], frames[p + 1])
+        np.testing.assert_allclose(want_p[p], wp, rtol=1e-10, atol=1e-12, err_msg=str(p))
+        assert abs(want_psnr[p] - wpsnr) < 1e-9, p
+    # waiting without the switch is refused
+    seq = native.Sequence(native.default_context(), 3, 64, 64)
+    with pytest.raises(native.GmeError):
+        seq.wait()
+    seq.close()
+
+
 @pytest.mark.parametrize("bs,fd", [(16, 1), (12, 5)])
 def test_pan240_sequence_vs_reference(golden, native, bs, fd, capsys, tmp_path):
     """The reference's real 51-frame sequence through the results.py flow (results.py:41-112) at the code
