@@ -393,9 +393,7 @@ class Sequence:
     #    page-locked arrays that are filled once wait() returns; one host thread can then drive several sequences
     def set_split_phase(self, on=True):
         _check(self.lib.gme_seq_set_split_phase(self.handle, int(bool(on))), self.lib)
-        self._split = bool(on)
-        if not on:
-            self._pin = {}
+        self._split = bool(on)                   # the page-locked buffers stay with the sequence for the next time
 
     def wait(self):
         _check(self.lib.gme_seq_wait(self.handle), self.lib)

@@ -39,8 +39,9 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
     if len(frames) <= fd:
         return psnr_dict
     # a few streams per GPU: each lane uploads its range of the video in one copy and then works on it,
-    # so one lane's host->device copy and 3x3 solves run beside the other lanes' kernels
-    seq = ShardedSequence(shape[0], shape[1], len(frames), fd, streams=STREAMS)
+    # so one lane's host->device copy runs beside the other lanes' kernels; the estimate is driven by one host
+    # thread over all streams (split-phase calls), whose 3x3 solves for one lane run beside the others' searches
+    seq = ShardedSequence(shape[0], shape[1], len(frames), fd, streams=STREAMS, interleave=True)
     seq.load(frames)
     params = seq.estimate()                                   # motion.global_motion_estimation per pair
     psnr = seq.compensate(params)                             # compensate_frame + PSNR per pair

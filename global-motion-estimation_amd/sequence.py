@@ -271,6 +271,8 @@ class ShardedSequence:
         """motion.global_motion_estimation for every local pair -> float64[P_local, 6]."""
         if not self.lanes:
             return np.zeros((0, 6))
+        if self.interleave and len(self.lanes) > 1:
+            return self._interleaved(procedure, search_window, False)[0]
         return np.concatenate(self._each(
             lambda lane: motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:lane.hi - lane.lo]), axis=0)
 
@@ -308,7 +310,7 @@ class ShardedSequence:
             return np.zeros((0, 6)), np.zeros(0)
 
         if self.interleave and len(self.lanes) > 1:
-            return self._interleaved(procedure, search_window, exact_psnr)
+            return self._interleaved(procedure, search_window, True, exact_psnr)
 
         def run(lane):
             n = lane.hi - lane.lo
@@ -317,38 +319,43 @@ class ShardedSequence:
         parts = self._each(run)
         return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]), exact_psnr)
 
-    def _interleaved(self, procedure, search_window, exact_psnr):
-        """estimate_and_compensate() for several ranges from one host thread: every stage is queued on all streams
-        before the first result is awaited, so range k's projection and 3x3 solves (motion.py:191-207,262-282, the
-        same arithmetic as motion.estimate_sequence) run while the other ranges' searches do."""
+    def _interleaved(self, procedure, search_window, compensate, exact_psnr=False):
+        """estimate() / estimate_and_compensate() for several ranges from one host thread: every stage is queued on
+        all streams before the first result is awaited, so range k's projection and 3x3 solves (motion.py:191-207,
+        262-282, the same arithmetic as motion.estimate_sequence) run while the other ranges' searches do.
+        -> (params[P, 6], psnr[P] or None)"""
         frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
         bs = int(motion.BBME_BLOCK_SIZE)
         lanes = self.lanes
         for lane in lanes:
-            if not getattr(lane.seq, "_split", False):
-                lane.seq.set_split_phase(True)
-        pending = [lane.seq.gme_begin(self.fd, bs, procedure, search_window) for lane in lanes]
-        params = [None] * len(lanes)
-        for level in (1, 2):
+            lane.seq.set_split_phase(True)
+        try:
+            pending = [lane.seq.gme_begin(self.fd, bs, procedure, search_window) for lane in lanes]
+            for level in (1, 2):
+                for k, lane in enumerate(lanes):
+                    lane.seq.wait()
+                    # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
+                    p = np.array(pending[k]) if level == 1 else motion._solve_batch(pending[k])
+                    p[:, 0] = p[:, 0] * 2
+                    p[:, 3] = p[:, 3] * 2
+                    pending[k] = lane.seq.gme_fit(level, p.astype(np.float64), frac)
+            params, sse = [None] * len(lanes), [None] * len(lanes)
             for k, lane in enumerate(lanes):
                 lane.seq.wait()
-                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
-                p = np.array(pending[k]) if level == 1 else motion._solve_batch(pending[k])
-                p[:, 0] = p[:, 0] * 2
-                p[:, 3] = p[:, 3] * 2
-                pending[k] = lane.seq.gme_fit(level, p.astype(np.float64), frac)
-        sse = [None] * len(lanes)
-        for k, lane in enumerate(lanes):
-            lane.seq.wait()
-            params[k] = motion._solve_batch(pending[k])
-            sse[k] = lane.seq.compensate(self.fd, bs, params[k])
-        out_sse = []
-        for k, lane in enumerate(lanes):
-            lane.seq.wait()
-            out_sse.append(np.array(sse[k][:lane.hi - lane.lo]))
-            lane.ctx.sync()                       # drains the stream and reports a walk that overran its guard
-        return (np.concatenate([p[:lane.hi - lane.lo] for p, lane in zip(params, lanes)], axis=0),
-                self._psnr(np.concatenate(out_sse), exact_psnr))
+                params[k] = motion._solve_batch(pending[k])
+                if compensate:
+                    sse[k] = lane.seq.compensate(self.fd, bs, params[k])
+            out_sse = []
+            for k, lane in enumerate(lanes):
+                if compensate:
+                    lane.seq.wait()
+                    out_sse.append(np.array(sse[k][:lane.hi - lane.lo]))
+                lane.ctx.sync()                   # drains the stream and reports a walk that overran its guard
+        finally:
+            for lane in lanes:
+                lane.seq.set_split_phase(False)   # the other methods of the class use the blocking calls
+        p_all = np.concatenate([p[:lane.hi - lane.lo] for p, lane in zip(params, lanes)], axis=0)
+        return p_all, (self._psnr(np.concatenate(out_sse), exact_psnr) if compensate else None)
 
     def read_compensated(self, pair):
         lane, k = self._lane_of(pair)
