@@ -93,6 +93,46 @@ __global__ void __launch_bounds__(256) k_pyrdown_edge(const uint8_t* src, long l
     dst[(long long)blockIdx.z * dst_stride + (long long)y * dpitch + x] = (uint8_t)((a + 128) >> 8);
 }
 
+// Border pixels for rows of >= 16 bytes whose width is a multiple of 4 (every pyramid level of the two BASELINE
+// shapes): all taps of a left-border pixel lie in the row's first 16 bytes, all taps of a right-border pixel in its
+// last 16 (2 x_end - 2 >= sW - 16, reflections included) -- five 16-byte loads per thread instead of 25 byte loads
+// that each touch their own cache line; the tap is picked out of the four dwords with a run-time byte index.
+__device__ __forceinline__ int byte_of(const u32x4_a4& v, int idx)
+{
+    const uint32_t lo = idx < 8 ? (idx < 4 ? v.x : v.y) : (idx < 12 ? v.z : v.w);
+    return (int)__builtin_amdgcn_ubfe(lo, (uint32_t)(idx & 3) * 8u, 8u);
+}
+
+__global__ void __launch_bounds__(256) k_pyrdown_edge16(const uint8_t* src, long long src_stride, int sH, int sW,
+                                                         int spitch, uint8_t* dst, long long dst_stride, int dH,
+                                                         int dW, int dpitch)
+{
+    const int x_end = pyr_interior_end(sW, dW);
+    const int n_left = min(4, dW), n_right = max(0, dW - x_end);
+    const int per_row = n_left + n_right;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int y = id / per_row, e = id - y * per_row;
+    if (y >= dH) return;
+    const bool left = e < n_left;
+    const int x = left ? e : x_end + (e - n_left);
+    const int base = left ? 0 : sW - 16;
+    const uint8_t* s = src + (long long)blockIdx.z * src_stride + base;
+    const int k[5] = { 1, 4, 6, 4, 1 };
+    int cx[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) cx[d] = reflect101(2 * x + d - 2, sW) - base;      // 0 .. 15
+    int a = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const u32x4_a4 v = *(const u32x4_a4*)(s + (long long)reflect101(2 * y + dy - 2, sH) * spitch);
+        int h = 0;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) h += k[d] * byte_of(v, cx[d]);
+        a += k[dy] * h;
+    }
+    dst[(long long)blockIdx.z * dst_stride + (long long)y * dpitch + x] = (uint8_t)((a + 128) >> 8);
+}
+
 // ---------------------------------------------------------------------------
 // motion.compute_first_parameters (motion.py:176-188)
 // ---------------------------------------------------------------------------
@@ -531,6 +571,10 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
                                src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
         }
         const dim3 egrid((dst.H * per_row + 255) / 256, 1, n);
+        if (src.W >= 16 && src.W % 4 == 0 && !getenv("GME_FORCE_GENERIC"))
+            hipLaunchKernelGGL(k_pyrdown_edge16, egrid, dim3(256), 0, ctx->stream, src.at(first), (long long)src.stride, src.H, src.W,
+                               src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
+        else
         hipLaunchKernelGGL(k_pyrdown_edge, egrid, dim3(256), 0, ctx->stream, src.at(first), (long long)src.stride, src.H, src.W,
                            src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
     }
