@@ -23,7 +23,7 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// Each thread produces 4 horizontally adjacent output pixels.  k_pyrdown covers the interior quads
+// Each thread produces 4 horizontally adjacent output pixels of two rows.  k_pyrdown covers the interior quads
 // (x in [4, x_end)): per source row the 16 aligned bytes [2x-4, 2x+12) hold the 11 taps
 // 2x-2 .. 2x+8 (one dword-aligned 16-byte load instead of 20 byte loads).  The quads that touch the
 // left/right border need BORDER_REFLECT_101 per tap; they run in their own small launch
@@ -41,27 +41,41 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long s
                                                   int spitch, uint8_t* dst, long long dst_stride, int dH,
                                                   int dW, int dpitch)
 {
+    // a thread produces the quad x .. x+3 of output rows y and y + 1: their 5-row supports overlap in 3 source rows, so
+    // 7 row loads and 7 horizontal passes serve both (10 with one output row per thread)
     const int x = 4 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
     if (x >= pyr_interior_end(sW, dW) || y >= dH) return;
     const uint8_t* s = src + (long long)blockIdx.z * src_stride;
     uint8_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y * dpitch + x;
-    const int k[5] = { 1, 4, 6, 4, 1 };
-    int acc[4] = { 0, 0, 0, 0 };
+    const bool two = y + 1 < dH;
+    int h[7][4];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-        const uint8_t* row = s + (long long)reflect101(2 * y + dy - 2, sH) * spitch + 2 * x - 4;
+    for (int r = 0; r < 7; ++r) {
+        if (r >= 5 && !two) {                              // rows only the second output row needs
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[r][p] = 0;
+            continue;
+        }
+        const uint8_t* row = s + (long long)reflect101(2 * y + r - 2, sH) * spitch + 2 * x - 4;
         const u32x4_a4 v = *(const u32x4_a4*)row;
         // output p takes bytes 2+2p .. 6+2p of the 16: the first four through v_dot4 against the taps (1 4 6 4),
         // the fifth (weight 1) by one bit-field extract
         const uint32_t w4[4] = { __builtin_amdgcn_alignbyte(v.y, v.x, 2u), v.y, __builtin_amdgcn_alignbyte(v.z, v.y, 2u), v.z };
         const uint32_t last[4] = { (v.y >> 16) & 0xFFu, v.z & 0xFFu, (v.z >> 16) & 0xFFu, v.w & 0xFFu };
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            acc[p] += k[dy] * (int)__builtin_amdgcn_udot4(w4[p], 0x04060401u, last[p], false);
+        for (int p = 0; p < 4; ++p) h[r][p] = (int)__builtin_amdgcn_udot4(w4[p], 0x04060401u, last[p], false);
     }
-    *(uint32_t*)o = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) |
-                    ((uint32_t)((acc[2] + 128) >> 8) << 16) | ((uint32_t)((acc[3] + 128) >> 8) << 24);
+    uint32_t out0 = 0, out1 = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int a0 = h[0][p] + 4 * h[1][p] + 6 * h[2][p] + 4 * h[3][p] + h[4][p];
+        const int a1 = h[2][p] + 4 * h[3][p] + 6 * h[4][p] + 4 * h[5][p] + h[6][p];
+        out0 |= (uint32_t)((a0 + 128) >> 8) << (8 * p);
+        out1 |= (uint32_t)((a1 + 128) >> 8) << (8 * p);
+    }
+    *(uint32_t*)o = out0;
+    if (two) *(uint32_t*)(o + dpitch) = out1;
 }
 
 // border pixels: x in [0, 4) and [x_end, dW); one thread per pixel
@@ -566,7 +580,7 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
     for (int first = 0; first < src.count; first += step) {            // grid.z holds at most 65535 planes
         const int n = src.count - first < step ? src.count - first : step;
         if (interior_quads > 0) {
-            const dim3 grid((interior_quads + 63) / 64, (dst.H + 3) / 4, n);
+            const dim3 grid((interior_quads + 63) / 64, (dst.H + 7) / 8, n);      // 4 waves x 2 output rows per workgroup
             hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, ctx->stream, src.at(first), (long long)src.stride, src.H, src.W,
                                src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W, dst.pitch);
         }
