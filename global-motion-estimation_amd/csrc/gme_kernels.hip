@@ -434,6 +434,16 @@ __global__ void __launch_bounds__(256) k_compensate(const uint8_t* frames, long 
 // against `cur` is three v_dot4_u32_u8 per dword (sum c^2 + sum v^2 - 2 sum c.v).  The untouched
 // original is only read where the rule of motion.py:309-318 keeps it (source outside the frame,
 // rows/columns beyond the field).  Workgroup tile: 256 x 32 pixels, one atomic.
+// buffer resource over `bytes` bytes from a wave-uniform pointer: reads outside it return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t span_rsrc(const uint8_t* p, int bytes)
+{
+    const uint64_t base = (uint64_t)p;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)base)),
+        (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 __global__ void __launch_bounds__(256) k_compensate16(const uint8_t* frames, long long frame_stride, int H, int W,
                                                        int pitch, const int32_t* mf32, const double* params, int h,
                                                        int w, uint8_t* out, long long out_stride, int out_pitch,
@@ -441,6 +451,7 @@ __global__ void __launch_bounds__(256) k_compensate16(const uint8_t* frames, lon
                                                        unsigned long long* sse)
 {
     __shared__ unsigned part[4];
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const int pair = blockIdx.z;
     const int x = (blockIdx.x * 16 + (threadIdx.x & 15)) * 16;
     const int y0 = blockIdx.y * 32 + (threadIdx.x >> 4);
@@ -449,14 +460,20 @@ __global__ void __launch_bounds__(256) k_compensate16(const uint8_t* frames, lon
     unsigned err = 0;
     if (x < W) {
         const int j = x / bs;
+        // Three passes over the thread's two rows so that all of its loads are in flight together: (1) where each run
+        // comes from, (2) the loads, without a branch around them -- through buffer resources, a run that is not
+        // fetched gets an out-of-range offset and reads 0 -- and (3) assembling, storing, squared error.
+        enum { NONE, INSIDE, STRADDLE, KEEP };
+        const int OUTSIDE = (int)0x80000000;
+        int kind[2], soff[2];
+        uint32_t sh[2];
+        long long sxs[2], sys[2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int y = y0 + 16 * half;
-            if (y >= H) break;
+            kind[half] = y < H ? KEEP : NONE; soff[half] = OUTSIDE; sh[half] = 0; sxs[half] = sys[half] = 0;
             const int i = y / bs;
-            uint4 v;
-            bool have = false;
-            if (i < h && j < w) {
+            if (y < H && i < h && j < w) {
                 int d0, d1;
                 if (mf32) {
                     const int32_t* m = mf32 + (((long long)pair * h + i) * w + j) * 2;
@@ -469,29 +486,49 @@ __global__ void __launch_bounds__(256) k_compensate16(const uint8_t* frames, lon
                 const long long sy = (long long)y - d1, sx = (long long)x - d0;
                 if (sy >= 0 && sy < H) {
                     if (sx >= 0 && sx + 16 <= W) {
-                        const uint32_t* sp = (const uint32_t*)(f + sy * pitch + (sx & ~3ll));
-                        const uint32_t sh = (uint32_t)sx & 3u;
-                        const uint32_t t0 = sp[0], t1 = sp[1], t2 = sp[2], t3 = sp[3];
-                        const uint32_t t4 = sh ? sp[4] : 0u;        // sp[4] may lie past the row when sx + 16 == pitch
-                        v.x = __builtin_amdgcn_alignbyte(t1, t0, sh); v.y = __builtin_amdgcn_alignbyte(t2, t1, sh);
-                        v.z = __builtin_amdgcn_alignbyte(t3, t2, sh); v.w = __builtin_amdgcn_alignbyte(t4, t3, sh);
-                        have = true;
-                    } else if (sx > -16 && sx < W) {            // straddles the left/right frame edge: per pixel
-                        v = *(const uint4*)(f + (long long)y * pitch + x);
-                        uint32_t vv[4] = { v.x, v.y, v.z, v.w };
-                        for (int q = 0; q < 16; ++q)
-                            if (sx + q >= 0 && sx + q < W)
-                                vv[q >> 2] = (vv[q >> 2] & ~(0xFFu << (8 * (q & 3)))) | ((uint32_t)f[sy * pitch + sx + q] << (8 * (q & 3)));
-                        v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
-                        have = true;
+                        kind[half] = INSIDE;
+                        soff[half] = (int)(sy * pitch + (sx & ~3ll));
+                        sh[half] = (uint32_t)sx & 3u;
+                    } else if (sx > -16 && sx < W) {            // straddles the left/right frame edge: per pixel, below
+                        kind[half] = STRADDLE; sxs[half] = sx; sys[half] = sy;
                     }
                 }
             }
-            if (!have) v = *(const uint4*)(f + (long long)y * pitch + x);
+        }
+        const __amdgpu_buffer_rsrc_t rf = span_rsrc(f, H * pitch);
+        const __amdgpu_buffer_rsrc_t rc = span_rsrc(cur ? cur + (long long)pair * cur_stride : f, cur ? H * pitch : 0);
+        u32x4_t t[2], c[2];
+        uint32_t t4[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // five aligned dwords hold the 16 source bytes; the fifth only when the run is not dword aligned (it lies
+            // inside the row then: W % 16 == 0)
+            t[half] = __builtin_amdgcn_raw_buffer_load_b128(rf, soff[half], 0, 0);
+            t4[half] = __builtin_amdgcn_raw_buffer_load_b32(rf, sh[half] ? soff[half] + 16 : OUTSIDE, 0, 0);
+            c[half] = __builtin_amdgcn_raw_buffer_load_b128(rc, kind[half] != NONE ? (y0 + 16 * half) * pitch + x : OUTSIDE, 0, 0);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int y = y0 + 16 * half;
+            if (kind[half] == NONE) continue;
+            uint4 v;
+            if (kind[half] == INSIDE) {
+                v.x = __builtin_amdgcn_alignbyte(t[half].y, t[half].x, sh[half]); v.y = __builtin_amdgcn_alignbyte(t[half].z, t[half].y, sh[half]);
+                v.z = __builtin_amdgcn_alignbyte(t[half].w, t[half].z, sh[half]); v.w = __builtin_amdgcn_alignbyte(t4[half], t[half].w, sh[half]);
+            } else {
+                v = *(const uint4*)(f + (long long)y * pitch + x);      // the untouched original (motion.py:309-318)
+                if (kind[half] == STRADDLE) {
+                    uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+                    const long long sx = sxs[half], sy = sys[half];
+                    for (int q = 0; q < 16; ++q)
+                        if (sx + q >= 0 && sx + q < W)
+                            vv[q >> 2] = (vv[q >> 2] & ~(0xFFu << (8 * (q & 3)))) | ((uint32_t)f[sy * pitch + sx + q] << (8 * (q & 3)));
+                    v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
             *(uint4*)(out + (long long)pair * out_stride + (long long)y * out_pitch + x) = v;
             if (cur) {
-                const uint4 c = *(const uint4*)(cur + (long long)pair * cur_stride + (long long)y * pitch + x);
-                const uint32_t cc[4] = { c.x, c.y, c.z, c.w }, vv[4] = { v.x, v.y, v.z, v.w };
+                const uint32_t cc[4] = { c[half].x, c[half].y, c[half].z, c[half].w }, vv[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned s2 = __builtin_amdgcn_udot4(cc[q], cc[q], __builtin_amdgcn_udot4(vv[q], vv[q], 0u, false), false);
