@@ -48,17 +48,24 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long s
     if (x >= pyr_interior_end(sW, dW) || y >= dH) return;
     const uint8_t* s = src + (long long)blockIdx.z * src_stride;
     uint8_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y * dpitch + x;
-    const bool two = y + 1 < dH;
+    const bool two = y + 1 < dH;                        // an odd dH: the last thread row stores one row (its loads stay valid: reflect101)
+    // source rows first (one reflection per side is all rows -2 .. sH + 3 of a plane of 4 or more rows need; no loop, no
+    // branch between the seven loads), then the loads, then the arithmetic
+    int sr[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        int q = 2 * y + r - 2;
+        q = q < 0 ? -q : q;
+        q = q >= sH ? 2 * (sH - 1) - q : q;
+        sr[r] = sH >= 4 ? q : reflect101(2 * y + r - 2, sH);
+    }
+    u32x4_a4 vs[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) vs[r] = *(const u32x4_a4*)(s + (long long)sr[r] * spitch + 2 * x - 4);
     int h[7][4];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-        if (r >= 5 && !two) {                              // rows only the second output row needs
-#pragma unroll
-            for (int p = 0; p < 4; ++p) h[r][p] = 0;
-            continue;
-        }
-        const uint8_t* row = s + (long long)reflect101(2 * y + r - 2, sH) * spitch + 2 * x - 4;
-        const u32x4_a4 v = *(const u32x4_a4*)row;
+        const u32x4_a4 v = vs[r];
         // output p takes bytes 2+2p .. 6+2p of the 16: the first four through v_dot4 against the taps (1 4 6 4),
         // the fifth (weight 1) by one bit-field extract
         const uint32_t w4[4] = { __builtin_amdgcn_alignbyte(v.y, v.x, 2u), v.y, __builtin_amdgcn_alignbyte(v.z, v.y, 2u), v.z };
