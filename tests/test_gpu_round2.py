@@ -116,6 +116,21 @@ def test_redo_path_small_batches_and_window_sizes(native, monkeypatch):
             seq.close()
 
 
+def test_pyramids_odd_and_tiny_shapes(native):
+    """k_pyrdown (two output rows per thread, seven row loads), k_pyrdown_edge16 (16-byte row chunks) and the per-pixel
+    border kernel on shapes with odd heights / widths, widths that are no multiple of 4, fewer than 16 columns and
+    fewer than 4 rows: every level equals the C oracle's restatement of cv2.pyrDown (utils.py:34-51)."""
+    import utils
+    co = c_oracle()
+    rng = np.random.default_rng(5)
+    for H, W in [(17, 17), (33, 47), (5, 9), (16, 20), (101, 203), (4, 16), (3, 40), (2, 2), (1, 7), (64, 66), (27, 128), (480, 722), (75, 1000)]:
+        f = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        pyr = utils.get_pyramids(f)
+        l1 = co.pyrdown(f)
+        assert np.array_equal(pyr[2], f) and np.array_equal(pyr[1], l1), (H, W)
+        assert np.array_equal(pyr[0], co.pyrdown(l1)), (H, W)
+
+
 @pytest.mark.parametrize("proc", [1, 2, 3])
 def test_walk16_random_shapes(native, proc):
     """k_walk16 (8 blocks per wave, prefetched through buffer resources) on shapes its grid does not divide evenly:
