@@ -406,7 +406,10 @@ class Sequence:
         pin = self.__dict__.setdefault("_pin", {})
         a = pin.get(name)
         if a is None or a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
-            a = pinned_empty(shape, dtype) if int(np.prod(shape)) else np.empty(shape, dtype=dtype)
+            try:
+                a = pinned_empty(shape, dtype) if int(np.prod(shape)) else np.empty(shape, dtype=dtype)
+            except MemoryError:                  # no page-locked memory left: the copies still work, they just hold the caller
+                a = np.empty(shape, dtype=dtype)
             pin[name] = a
         return a
 
