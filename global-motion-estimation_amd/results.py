@@ -19,7 +19,7 @@ from sequence import ShardedSequence
 from utils import draw_motion_field, get_video_frames, write_image
 
 FRAME_DISTANCE = 1          # results.py:11
-STREAMS = 3                 # HIP streams (and host threads) the video's pairs are cut into
+STREAMS = 3                 # HIP streams (pair ranges) per GPU: uploads run one host thread per range, the estimate one thread over all
 
 
 def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progress=False):
