@@ -7,9 +7,12 @@
 One "step" = one pass of the hot path over this rank's batch of frame pairs, frames already resident
 in HBM.  Default workload = BASELINE.json configs[1]: 720x480 synthetic luma, bs=16, sw=16, exhaustive
 search, MAE.  Frame pairs shard across ranks with no data-path collective ("weak" scaling: every rank
-holds its own batch); the only exchange of the path is the all-gather of per-pair parameter rows of
-config seq1080 (BASELINE configs[4]), which goes through the library's own RCCL entry point
-(gme_comm_*, include/gme_hip.h) like the barriers and the max-over-ranks time.
+holds its own batch).  The path's one exchange is the all-gather of 48-byte per-pair rows: at N > 1
+every step of a block-matching config ends with it (gme_seq_mv_summary_gather: summary kernel ->
+ncclAllGather of the device rows -> one copy to the host, queued behind the search so the next step's
+search runs behind the collective), and the GME sequence config gathers its parameter rows
+(gme_shard_gather).  Barriers and the max-over-ranks time go through the same communicator
+(gme_comm_*, include/gme_hip.h).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      HBM view of the dominant kernel: algorithmic bytes / HIP-event kernel time, measured live
@@ -17,15 +20,19 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 instructions per wave from the committed PMC profile of this command (labelled as such)
   parity        the HIP results of >= 64 sampled pairs (first and last included) against the C oracle
   content_sweep the same kernel on other content (real frames, noise, flat): pairs/s and the share of
-                candidate patches the elimination bound left for exact evaluation
+                candidate patches the elimination bound left for exact evaluation; content_sweep_mse likewise
+  secondary     (default command only) the other BASELINE configs at a handful of steps each, so that the one
+                driver-run line carries configs[2] and configs[3] too: pairs/s, ms/step, sampled oracle parity
   cpu_baseline  the NumPy oracle (reference loop structure) on one host core over a bounded sample
 """
 import argparse
 import hashlib
 import json
 import os
+import platform
 import sys
 import time
+import types
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(REPO, "global-motion-estimation_amd"), REPO]
@@ -41,6 +48,8 @@ CONFIGS = {
     "exh1080": (1080, 1920, 16, 32, 0, 0, 4321, "1920x1080 synthetic luma, bs=16 sw=32 exhaustive MAE"),
     "dia720": (480, 720, 16, 16, 3, 0, 1234, "720x480 synthetic luma, bs=16 diamond MAE"),
     "dia720mse": (480, 720, 16, 16, 3, 1, 1234, "720x480 synthetic luma, bs=16 diamond MSE"),
+    "tss720": (480, 720, 16, 16, 1, 1, 1234, "720x480 synthetic luma, bs=16 sw=16 three-step search MSE (bbme.py:182-341)"),
+    "tdl720": (480, 720, 16, 16, 2, 1, 1234, "720x480 synthetic luma, bs=16 sw=16 2-D logarithmic search MSE (bbme.py:344-433)"),
     # full GME: procedure/pnorm fields unused (the reference hard-codes diamond + MSE, motion.py:27,224)
     "gme720": (480, 720, 16, 2, -1, 1, 1234, "720x480 full multiscale affine GME (3-level pyramid + diamond BBME + "
                "outlier mask + compensate + PSNR), BASELINE configs[2]"),
@@ -62,7 +71,12 @@ QSAD_PEAK_OPS = 1024 * 1024 / 6.9e-9
 PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per bench line
 # rough C-oracle seconds per pair (one core), to size the parity sample
 ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080mse": 1.8, "dia720": 0.01,
-                     "dia720mse": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15, "gme1080exh": 2.1}
+                     "dia720mse": 0.01, "tss720": 0.01, "tdl720": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15,
+                     "gme1080exh": 2.1}
+# the default line's "secondary" block: (config, pairs per step, steps, warmup, seconds of C-oracle parity)
+SECONDARY = [("gme720", 2048, 8, 2, 2.0), ("exh720mse", 2048, 6, 2, 2.0), ("dia720mse", 2048, 8, 2, 1.0),
+             ("tss720", 2048, 8, 2, 1.0), ("tdl720", 2048, 8, 2, 1.0),
+             ("exh1080mse", 512, 3, 1, 6.0), ("gme1080exh", 512, 3, 1, 7.0)]
 
 
 def algorithmic_bytes(H, W, bs, gme=False):
@@ -92,8 +106,9 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def committed_profile(config):
-    """Counters of the newest committed PMC summary of `bench.py --config <config>` (profiles/), its
+def committed_profile(config, kernel=None):
+    """Counters of the newest committed PMC summary of `bench.py --config <config>` (profiles/) for the kernel whose
+    name starts with `kernel` (the launch plan's kernel; default: the busiest kernel of the file), its
     kernel_source_sha line and file name; ({}, None, None) if there is none."""
     prof_dir = os.path.join(REPO, "profiles")
     if not os.path.isdir(prof_dir):
@@ -101,19 +116,66 @@ def committed_profile(config):
     cands = sorted(n for n in os.listdir(prof_dir) if n.endswith("_%s_pmc_summary.txt" % config))
     if not cands:
         return {}, None, None
-    vals, sha = {}, None
+    per_kernel, sha = {}, None
     for line in open(os.path.join(prof_dir, cands[-1])):
         if line.startswith("# kernel_source_sha:"):
             sha = line.split(":", 1)[1].strip()
         f = line.split()
-        if not line.startswith("#") and len(f) >= 4 and f[-1].startswith("mean=") and "k_exh_sea16p" in line:
-            vals[f[-3]] = float(f[-1].split("=")[1])
+        if not line.startswith("#") and len(f) >= 4 and f[-1].startswith("mean="):
+            name = " ".join(f[:-3]).replace(" ", "")           # "k_exh_sea16p<3, 5, 36>" -> "k_exh_sea16p<3,5,36>"
+            per_kernel.setdefault(name, {})[f[-3]] = float(f[-1].split("=")[1])
+    if not per_kernel:
+        return {}, sha, cands[-1]
+    if kernel:
+        base = kernel.split("<")[0]
+        hits = [n for n in per_kernel if n.split("<")[0] == base]
+        if not hits:
+            return {}, sha, cands[-1]
+        name = max(hits, key=lambda n: per_kernel[n].get("GRBM_GUI_ACTIVE", 0.0))
+    else:
+        name = max(per_kernel, key=lambda n: per_kernel[n].get("GRBM_GUI_ACTIVE", 0.0))
+    vals = dict(per_kernel[name])
+    vals["_kernel"] = name
     return vals, sha, cands[-1]
+
+
+def host_description():
+    """What the CPU baseline ran on (nproc and CPU model of the box, interpreter, NumPy)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cores_usable_by_this_process": usable,
+            "python": platform.python_version(), "numpy": np.__version__, "machine": platform.machine()}
 
 
 # ---------------------------------------------------------------------------------------------
 # content other than the synthetic sequence (exhaustive configs): uint8[n, H, W] host stacks
 # ---------------------------------------------------------------------------------------------
+def upscale2(f):
+    """uint8[n, h, w] -> uint8[n, 2h, 2w]: the frames themselves on the even grid, rounded means in between
+    (real content at twice the size without flat 2x2 cells)."""
+    f = f.astype(np.uint16)
+    n, h, w = f.shape
+    up = np.empty((n, 2 * h, 2 * w), np.uint16)
+    right = np.concatenate([f[:, :, 1:], f[:, :, -1:]], axis=2)
+    down = np.concatenate([f[:, 1:], f[:, -1:]], axis=1)
+    diag = np.concatenate([down[:, :, 1:], down[:, :, -1:]], axis=2)
+    up[:, 0::2, 0::2] = f
+    up[:, 0::2, 1::2] = (f + right + 1) >> 1
+    up[:, 1::2, 0::2] = (f + down + 1) >> 1
+    up[:, 1::2, 1::2] = (f + right + down + diag + 2) >> 2
+    return up.astype(np.uint8)
+
+
 def host_content(kind, n, H, W):
     g = os.path.join(REPO, "tests", "golden")
     if kind == "noise":            # nothing correlates: the bound prunes (almost) nothing
@@ -121,15 +183,22 @@ def host_content(kind, n, H, W):
         return rng.integers(0, 256, (n, H, W), dtype=np.uint8), H, W
     if kind == "flat":             # all costs tie at zero
         return np.full((n, H, W), 128, np.uint8), H, W
-    if kind == "race":             # the reference's 720x480 doc frames, alternating
+    if kind == "race":             # the reference's 720x480 doc frames: TWO distinct frames, alternating (L2-resident)
         z = np.load(os.path.join(g, "g3_docframes.npz"))
         pair = [z["in_race_prev"], z["in_race_cur"]]
         return np.stack([pair[i & 1] for i in range(n)]), 480, 720
-    if kind == "pan240seq":        # the reference's 51 real frames (320x240), walked back and forth
+    if kind in ("pan240seq", "pan240x2"):     # the reference's 51 real frames (320x240), walked back and forth
         f = np.load(os.path.join(g, "g9_pan240seq.npz"))["frames"]
+        if kind == "pan240x2":                # ... upscaled to 640x480: 51 distinct real frames near the headline size
+            f = upscale2(f)
         order = list(range(51)) + list(range(49, 0, -1))
-        return np.stack([f[order[i % len(order)]] for i in range(n)]), 240, 320
+        return np.stack([f[order[i % len(order)]] for i in range(n)]), f.shape[1], f.shape[2]
     raise KeyError(kind)
+
+
+CONTENT_NOTE = {"race": "2 distinct real frames alternating (L2-resident)", "pan240seq": "51 distinct real frames, 320x240",
+                "pan240x2": "51 distinct real frames upscaled x2 to 640x480", "noise": "uniform noise, nothing correlates",
+                "flat": "constant frames, every cost ties"}
 
 
 def sample_pairs(n_pairs, want):
@@ -137,8 +206,8 @@ def sample_pairs(n_pairs, want):
     return sorted(set(int(round(x)) for x in np.linspace(0, n_pairs - 1, want)))
 
 
-def parity_sample_size(config):
-    return int(max(4, min(64, PARITY_BUDGET_S / ORACLE_S_PER_PAIR.get(config, 0.1))))
+def parity_sample_size(config, budget_s=PARITY_BUDGET_S):
+    return int(max(3, min(64, budget_s / ORACLE_S_PER_PAIR.get(config, 0.1))))
 
 
 def cpu_baseline_exhaustive(cfg, budget_s=14.0):
@@ -220,12 +289,14 @@ def cpu_baseline_gme(cfg, frames):
 
 class Comm:
     """Barrier / max / gather across the ranks of one node.  world == 1: nothing.  world > 1: the
-    library's RCCL communicator (gme_comm_*: ncclAllReduce / ncclAllGather on the context's stream);
-    torch.distributed is the fallback transport if that cannot be brought up (and GME_BENCH_BACKEND=gloo
-    the CPU rehearsal)."""
+    library's RCCL communicator (gme_comm_*: ncclAllReduce / ncclAllGather on the context's stream).
+    Whether that communicator is used is decided by ALL ranks together (sequence.comm_init raises
+    CommUnavailable on every rank if any rank cannot bring it up); only then do all ranks take
+    torch.distributed as the transport instead.  GME_BENCH_BACKEND=gloo is the CPU rehearsal."""
 
     def __init__(self, ctx, rank, world, local):
         self.ctx, self.rank, self.world, self.kind, self.dist, self.torch = ctx, rank, world, "none", None, None
+        self.rccl_reports = None
         if world == 1 and not os.environ.get("GME_BENCH_FORCE_DIST"):
             return
         backend = os.environ.get("GME_BENCH_BACKEND", "rccl")
@@ -236,14 +307,20 @@ class Comm:
         os.dup2(2, 1)
         try:
             if backend == "rccl":
+                import sequence
                 try:
-                    import sequence
                     sequence.comm_init(ctx, rank, world)
                     self.kind = "rccl (C ABI: gme_comm_*)"
+                    r, n = sequence.comm_info(ctx)
+                    self.rccl_reports = {"rank": r, "ranks": n}
+                    if (r, n) != (rank, world):
+                        raise SystemExit("bench.py: RCCL reports rank %d of %d, the launcher said %d of %d" % (r, n, rank, world))
                     return
-                except Exception as e:          # noqa: BLE001 -- say so and fall back
-                    print("bench.py: C-ABI RCCL communicator failed (%r); falling back to torch.distributed" % (e,), file=sys.stderr)
+                except sequence.CommUnavailable as e:      # raised on EVERY rank: all of them take the same fallback
+                    print("bench.py rank %d: C-ABI RCCL communicator unavailable on this launch (%s); all ranks fall back to "
+                          "torch.distributed" % (rank, e), file=sys.stderr)
                     backend = "nccl"
+                # anything else (a rendezvous timeout, a HIP error) is not agreed between the ranks: die non-zero
             self._torch_init(backend, rank, world, local)
         finally:
             sys.stdout.flush()
@@ -263,9 +340,13 @@ class Comm:
         self.kind = "torch.distributed/" + backend
         self.device = torch.device("cuda", local) if backend == "nccl" else None
 
+    @property
+    def rccl(self):
+        return self.kind.startswith("rccl")
+
     def barrier(self):
         self.ctx.sync()
-        if self.kind.startswith("rccl"):
+        if self.rccl:
             import sequence
             sequence.comm_barrier(self.ctx)
         elif self.dist is not None:
@@ -274,7 +355,7 @@ class Comm:
                 self.torch.cuda.synchronize()
 
     def max(self, value):
-        if self.kind.startswith("rccl"):
+        if self.rccl:
             import sequence
             return sequence.comm_max(self.ctx, value)
         if self.dist is not None:
@@ -285,53 +366,32 @@ class Comm:
 
     def gather_rows(self, rows, n_pairs_total):
         import sequence
-        if self.kind.startswith("rccl"):
+        if self.rccl:
             return sequence.gather_parameters_rccl(self.ctx, rows, n_pairs_total, self.rank, self.world)
         if self.dist is not None:
-            return sequence.gather_parameters(rows, n_pairs_total, self.rank, self.dist.get_world_size(), self.device)
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            from helpers import gather_rows_torch
+            return gather_rows_torch(rows, n_pairs_total, self.rank, self.dist.get_world_size(), self.device)
         return rows
 
     def close(self):
-        if self.kind.startswith("rccl"):
+        if self.rccl:
             import sequence
             sequence.comm_destroy(self.ctx)
         elif self.dist is not None:
             self.dist.destroy_process_group()
+        self.kind = "none"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=None,
-                    help="frame pairs resident and processed per step per GPU (default %d: launch ramps, tails and "
-                         "the host-side solves of the GME stages cost the same per step whatever the batch)" % DEFAULT_PAIRS)
-    ap.add_argument("--config", default="exh720", choices=sorted(CONFIGS))
-    ap.add_argument("--content", default="synthetic", choices=["synthetic", "race", "pan240seq", "noise", "flat"],
-                    help="frame content of the exhaustive / walk configs (uploaded from the host unless synthetic)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-content-sweep", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit("bench.py --gpus %d does not match WORLD_SIZE=%d: launch it with torch.distributed.run "
-                 "--nproc-per-node %d (or plainly for --gpus 1)" % (args.gpus, world, args.gpus))
-    cfg = CONFIGS[args.config]
+def measure(opt, ctx, comm, rank, world):
+    """One bench line: set the workload up, time `opt.steps` steps, check parity; -> dict on rank 0, None elsewhere.
+    `opt`: config, content, pairs, steps, warmup, cpu_baseline, content_sweep, pcie, parity_budget_s."""
+    import _gme_native as native
+    cfg = CONFIGS[opt.config]
     H, W, bs, sw, proc, pnorm, seed, label = cfg
     gme = proc < 0
-    if gme and args.content != "synthetic":
-        sys.exit("--content applies to the block-matching configs only")
-
-    import _gme_native as native
-    ndev = native.load_library().gme_device_count()
-    ctx = native.Context(local % max(ndev, 1))          # rehearsals may put several ranks on one card
-    comm = Comm(ctx, rank, world, local % max(ndev, 1))
-    B = args.pairs if args.pairs is not None else DEFAULT_PAIRS
+    B = opt.pairs if opt.pairs is not None else DEFAULT_PAIRS
+    distributed = comm.kind != "none"
     # GME runs cut the resident pairs into `streams` ranges, each on its own HIP stream and host
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
@@ -352,12 +412,12 @@ def main():
         import sequence
         shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams, interleave=interleave)
         shard.synth(seed, rank * B)                # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
-    elif args.content == "synthetic":
+    elif opt.content == "synthetic":
         seq = native.Sequence(ctx, B + 1, H, W)
         seq.synth(seed, rank * B)
     else:
-        frames, H, W = host_content(args.content, B + 1, H, W)
-        label = label.replace("synthetic luma", "%s content" % args.content).replace("720x480", "%dx%d" % (W, H))
+        frames, H, W = host_content(opt.content, B + 1, H, W)
+        label = label.replace("synthetic luma", "%s content" % opt.content).replace("720x480", "%dx%d" % (W, H))
         seq = native.Sequence.from_frames(ctx, frames)
         del frames
     if shard is not None:
@@ -365,6 +425,7 @@ def main():
     ctx.sync()
 
     last = {}
+    finish = None
     if proc == -3:
         def step():
             shard.invalidate()
@@ -381,6 +442,33 @@ def main():
                 last["params"], last["psnr"] = shard.estimate_and_compensate(0, sw)
             else:
                 last["params"], last["psnr"] = shard.estimate_and_compensate()
+    elif distributed and comm.rccl:
+        # N > 1: every step ends with the path's one exchange -- the all-gather of one 48-byte summary row per pair
+        # (modal vector, its count, vector sums, checksum), device to device over RCCL on the search's own stream.  It
+        # is queued behind the search and awaited one step later, so the next search runs behind the collective.
+        seq.set_split_phase(True)
+        pend = {"k": 0, "buf": None}
+
+        def step():
+            seq.invalidate_pyramids()
+            seq.bbme(1, bs, sw, proc, pnorm)
+            if pend["buf"] is not None:
+                seq.wait()                         # rows of the previous step (the event behind its copy)
+                last["gathered"] = pend["buf"]
+            pend["buf"] = seq.mv_summary_gather(B, world, slot=pend["k"] & 1)
+            pend["k"] += 1
+
+        def finish():
+            if pend["buf"] is not None:
+                seq.wait()
+                last["gathered"] = pend["buf"]
+                pend["buf"] = None
+    elif distributed:
+        def step():                                # the agreed fallback transport / the gloo rehearsal: rows via the host
+            seq.invalidate_pyramids()
+            seq.bbme(1, bs, sw, proc, pnorm)
+            rows = comm.gather_rows(seq.mv_summary(), world * B)
+            last["gathered"] = rows.reshape(world, B, 6)
     else:
         def step():
             # per-frame auxiliary tables (the MSE identity's box sums of squares) are derived from the
@@ -388,32 +476,44 @@ def main():
             seq.invalidate_pyramids()
             seq.bbme(1, bs, sw, proc, pnorm)       # asynchronous launches on the context's stream
 
-    for _ in range(args.warmup):
+    for _ in range(opt.warmup):
         step()
+    if finish:
+        finish()
     if shard is not None:
         shard.sync()
     comm.barrier()
     ctx.timer_start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(opt.steps):
         step()
-    kernel_ms = ctx.timer_stop() / max(args.steps, 1)      # HIP events on the launch stream; synchronises
+    if finish:
+        finish()
+    kernel_ms = ctx.timer_stop() / max(opt.steps, 1)      # HIP events on the launch stream; synchronises
     if shard is not None:
         shard.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
     if gme:
-        kernel_ms = 1e3 * elapsed / max(args.steps, 1)     # several streams: the whole step on the wall clock
+        kernel_ms = 1e3 * elapsed / max(opt.steps, 1)     # several streams: the whole step on the wall clock
     elapsed = comm.max(elapsed)
+    if seq is not None and distributed and comm.rccl:
+        seq.set_split_phase(False)
+
+    def release():
+        if seq is not None:
+            seq.close()
+        if shard is not None:
+            shard.close()
 
     if rank != 0:
-        comm.close()
-        return
+        release()
+        return None
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from helpers import c_oracle, oracle_results_flow
+    from helpers import c_oracle, mv_summary_rows, oracle_results_flow
 
     # ---- parity gate printed with the number: sampled pairs (first and last included) against the C oracle
-    n_s = parity_sample_size(args.config)
+    n_s = parity_sample_size(opt.config, opt.parity_budget_s)
     parity = {"checker": "oracle/gme_oracle.c (C restatement pinned on the reference's goldens)"}
     t_par = time.perf_counter()
     if not gme:
@@ -428,9 +528,32 @@ def main():
         parity.update({"pairs_checked": len(idx), "first": idx[0], "last": idx[-1], "mismatching_pairs": bad, "ok": not bad,
                        "what": "motion-vector field, bit-exact"})
         gpath = os.path.join(REPO, "tests", "golden", "g2_synth720.npz")
-        if args.config in ("exh720", "exh720mse", "dia720", "dia720mse") and args.content == "synthetic" and os.path.exists(gpath):
-            parity["pair0_equals_reference_golden"] = bool(np.array_equal(seq.read_mv(0, 1)[0], np.load(gpath)["mf_sp%d_pn%d" % (proc, pnorm)]))
-            parity["ok"] = parity["ok"] and parity["pair0_equals_reference_golden"]
+        if (opt.config in ("exh720", "exh720mse", "dia720", "dia720mse", "tss720", "tdl720") and opt.content == "synthetic"
+                and os.path.exists(gpath)):
+            key = "mf_sp%d_pn%d" % (proc, pnorm)
+            g2 = np.load(gpath)
+            if key in g2.files:
+                parity["pair0_equals_reference_golden"] = bool(np.array_equal(seq.read_mv(0, 1)[0], g2[key]))
+                parity["ok"] = parity["ok"] and parity["pair0_equals_reference_golden"]
+        if distributed:
+            # the gathered rows: rank 0's own block against its own fields, and sampled pairs OWNED BY OTHER RANKS
+            # against the C oracle on frames regenerated by the host generator (rank r holds t = r*B .. r*B+B)
+            import synth
+            g = np.asarray(last["gathered"])
+            own_ok = bool(np.array_equal(g[0], mv_summary_rows(seq.read_mv(0, B))))
+            others, bad_rows = [], []
+            if opt.content == "synthetic":
+                for r in range(1, world):
+                    for j in sorted({0, B // 2, B - 1}):
+                        want = mv_summary_rows(co.bbme(synth.frame(seed, r * B + j, H, W), synth.frame(seed, r * B + j + 1, H, W),
+                                                       bs, sw, proc, pnorm))[0]
+                        others.append([r, j])
+                        if not np.array_equal(g[r, j], want):
+                            bad_rows.append([r, j])
+            parity["gathered_rows"] = {"shape": list(g.shape), "own_block_equals_own_fields": own_ok,
+                                       "pairs_of_other_ranks_checked_vs_oracle": others, "mismatching": bad_rows,
+                                       "row": "modal vector x, y, its block count, sum x, sum y, checksum (gme_seq_mv_summary)"}
+            parity["ok"] = parity["ok"] and own_ok and not bad_rows
     else:
         info = shard.lanes[0].ctx.last_bbme_info()
         n_local = shard.n_pairs
@@ -460,7 +583,7 @@ def main():
                 if not (np.allclose(rows[p, :6], wp, rtol=1e-10, atol=1e-12) and abs(rows[p, 6] - wpsnr) < 1e-9):
                     bad.append(p)
             parity.update({"gathered_pairs_of_other_ranks_checked": other, "mismatching_pairs": bad, "ok": not bad})
-        if args.config == "gme720":
+        if opt.config == "gme720":
             g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_gme.npz"))
             comp_sha = hashlib.sha256(shard.read_compensated(0).tobytes()).hexdigest()
             parity["pair0_equals_reference_golden"] = bool(np.allclose(last["params"][0], g4["synth720_params"], rtol=1e-10, atol=1e-12)
@@ -468,27 +591,38 @@ def main():
             parity["ok"] = parity["ok"] and parity["pair0_equals_reference_golden"]
     parity["seconds"] = round(time.perf_counter() - t_par, 2)
 
-    total_pairs = (shard.n_pairs_total if proc == -3 else world * B) * args.steps
+    total_pairs = (shard.n_pairs_total if proc == -3 else world * B) * opt.steps
     value = total_pairs / elapsed
     abytes = algorithmic_bytes(H, W, bs, gme) * B
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    if proc == -3:
+        exchange = "all-gather of float64[7] rows (6 parameters + PSNR) per pair at the end of a step (gme_shard_gather)"
+    elif distributed and not gme:
+        exchange = ("all-gather of one float64[6] summary row per pair at the end of every step, device to device, queued behind "
+                    "the search (gme_seq_mv_summary_gather)" if comm.rccl else
+                    "all-gather of one float64[6] summary row per pair at the end of every step, through the host (gme_seq_mv_summary)")
+    else:
+        exchange = "none in this run"
     out = {
         "metric": "frame-pairs/s + achieved HBM GB/s, 720x480 bs=16 sw=16 exhaustive"
-                  if args.config == "exh720" else "frame-pairs/s, " + args.config,
-        "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                  if opt.config == "exh720" else "frame-pairs/s, " + opt.config,
+        "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
+        "ms_per_step": 1e3 * elapsed / opt.steps, "higher_is_better": True,
         "scaling": "strong" if proc == -3 else "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.content == "synthetic" else args.content,
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic" if opt.content == "synthetic" else opt.content,
         "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
                    "sharding": "frame pairs across ranks, no data-path collective",
                    "streams_per_gpu": len(shard.lanes) if shard is not None else 1,
-                   "collective": comm.kind, "multi_gpu_measured_by_builder": False},
+                   "collective": comm.kind, "exchange": exchange, "rccl_reports": comm.rccl_reports,
+                   "multi_gpu_measured_by_builder": False},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": info["plan"] if not gme else "whole step (all kernels + host solves)",
                      "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": abytes},
         "parity": parity,
     }
+    if distributed and not gme:
+        out["roofline"]["note"] = "kernel_ms_per_launch spans the step's search, summary kernel and all-gather (HIP events on the stream)"
     if gme:
         # the dominant kernel of the GME step is the level-2 block search (diamond: k_walk16<1>; configs[3]: the
         # exhaustive MSE kernel): time that launch alone with HIP events on one lane's stream and rate it against the
@@ -508,8 +642,9 @@ def main():
             "kernel": kinfo["plan"] + " (level-2 search of the step, timed alone on %d pairs)" % n0,
             "kernel_ms_per_launch": k_ms, "algorithmic_bytes_per_launch": kbytes,
             "achieved": kbytes / (k_ms * 1e-3) / 1e9, "frac": kbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "whole_step": {"ms": kernel_ms, "algorithmic_bytes": abytes, "achieved_GBps": achieved,
+            "whole_step": {"ms": kernel_ms, "algorithmic_bytes": abytes, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
                            "note": "all kernels + host solves, %d streams" % len(shard.lanes)}})
+        info = kinfo
     if info.get("patches"):
         out["elimination"] = {"patches": info["patches"], "surviving": info["surviving"],
                               "surviving_fraction": info["surviving"] / info["patches"],
@@ -517,7 +652,8 @@ def main():
 
     # ---- HBM traffic and issue statistics of the dominant kernel from the committed rocprofv3 PMC passes of
     # this same command (profiles/): valid only for the kernels they were taken from (kernel_source_sha)
-    vals, psha, pname = committed_profile(args.config)
+    plan_kernel = info["plan"].split(" ")[0] if info.get("plan") else None
+    vals, psha, pname = committed_profile(opt.config, plan_kernel)
     switches = sorted(k for k in os.environ if k.startswith("GME_") and k not in ("GME_DEVICE",))
     if proc == 0:
         ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
@@ -525,7 +661,7 @@ def main():
             "note": "byte abs-diffs a search that evaluates EVERY candidate would need, per second; the elimination kernel "
                     "never evaluates most of them, so this is not a utilisation figure (it may exceed the QSAD issue peak)",
             "value": ops, "unit": "byte-abs-diff/s", "qsad_issue_peak": QSAD_PEAK_OPS}
-    if vals and args.content == "synthetic":
+    if vals and opt.content == "synthetic":
         reason = None
         if psha != kernel_source_sha():
             reason = "kernel sources changed since %s was taken" % pname
@@ -535,8 +671,8 @@ def main():
             reason = "profile is of the default single-GPU command"
         if reason is None and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            out["roofline"]["traffic_source"] = ("committed profile profiles/%s: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
-                                                 "x2 = the guide's gfx950 FETCH_SIZE correction" % pname)
+            out["roofline"]["traffic_source"] = ("committed profile profiles/%s, kernel %s: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
+                                                 "x2 = the guide's gfx950 FETCH_SIZE correction" % (pname, vals["_kernel"]))
         else:
             out["roofline"]["traffic_source"] = "null: " + (reason or "no FETCH_SIZE/WRITE_SIZE in the committed profile")
         if reason is None and all(k in vals for k in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
@@ -545,42 +681,50 @@ def main():
             wave_tiles = info["patches"] / (64 * ((2 * sw + 16 + 15) // 16)) if info.get("patches") else None
             out["issue"] = {
                 "bound": "valu_issue", "source": "committed profile profiles/%s (same kernel sources, same command)" % pname,
+                "kernel": vals["_kernel"],
                 "achieved": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), "peak": 1.0, "unit": "VALU-busy fraction of SIMD cycles",
                 "frac": vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc),
                 "salu_per_valu_inst": vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"],
-                "lds_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"],
+                "lds_conflict_share": vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"] if vals["SQ_LDS_IDX_ACTIVE"] else None,
                 "insts_per_wave_tile": None if not wave_tiles else {"valu": vals["SQ_INSTS_VALU"] / wave_tiles,
                                                                     "salu": vals["SQ_INSTS_SALU"] / wave_tiles,
                                                                     "lds": vals["SQ_INSTS_LDS"] / wave_tiles}}
+    elif opt.content == "synthetic":
+        out["roofline"]["traffic_source"] = "null: no committed PMC profile of this config for kernel %s" % plan_kernel
 
-    # ---- the same kernel on other content: real frames, noise (no pruning), flat (all ties)
-    if proc == 0 and world == 1 and args.content == "synthetic" and not args.no_content_sweep:
-        sweep = {}
-        nsw = min(B, 512)
-        for kind in ("race", "pan240seq", "noise", "flat"):
-            if kind == "race" and (H, W) != (480, 720):
-                continue
-            fr, h2, w2 = host_content(kind, nsw + 1, H, W)
-            s2 = native.Sequence.from_frames(ctx, fr)
-            s2.bbme(1, bs, sw, proc, pnorm)
-            ctx.sync()
-            ctx.timer_start()
-            for _ in range(3):
-                s2.invalidate_pyramids()
-                s2.bbme(1, bs, sw, proc, pnorm)
-            ms = ctx.timer_stop() / 3
-            inf = ctx.last_bbme_info()
-            co = c_oracle()
-            chk = sample_pairs(nsw, 6)
-            ok = all(np.array_equal(s2.read_mv(p, 1)[0], co.bbme(fr[p], fr[p + 1], bs, sw, proc, pnorm)) for p in chk)
-            sweep[kind] = {"frame": "%dx%d" % (w2, h2), "pairs": nsw, "pairs_per_s": nsw / (ms * 1e-3), "kernel": inf["plan"].split(" grid")[0],
-                           "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
-                           "tiles_redone_by_brute_force": inf["redo_tiles"],
-                           "parity_ok_sampled": bool(ok)}
-            s2.close()
-        out["content_sweep"] = sweep
+    # ---- the same kernel on other content: real frames, noise (no pruning), flat (all ties); and the MSE kernel
+    if proc == 0 and world == 1 and opt.content == "synthetic" and opt.content_sweep:
+        def sweep_of(pn, kinds):
+            sweep = {}
+            nsw = min(B, 512)
+            for kind in kinds:
+                if kind in ("race", "pan240x2") and (H, W) != (480, 720):
+                    continue
+                fr, h2, w2 = host_content(kind, nsw + 1, H, W)
+                s2 = native.Sequence.from_frames(ctx, fr)
+                s2.bbme(1, bs, sw, proc, pn)
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(3):
+                    s2.invalidate_pyramids()
+                    s2.bbme(1, bs, sw, proc, pn)
+                ms = ctx.timer_stop() / 3
+                inf = ctx.last_bbme_info()
+                co = c_oracle()
+                chk = sample_pairs(nsw, 6)
+                ok = all(np.array_equal(s2.read_mv(p, 1)[0], co.bbme(fr[p], fr[p + 1], bs, sw, proc, pn)) for p in chk)
+                sweep[kind] = {"frame": "%dx%d" % (w2, h2), "content": CONTENT_NOTE[kind], "pairs": nsw,
+                               "pairs_per_s": nsw / (ms * 1e-3), "kernel": inf["plan"].split(" grid")[0],
+                               "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
+                               "tiles_redone_by_brute_force": inf["redo_tiles"],
+                               "parity_ok_sampled": bool(ok)}
+                s2.close()
+            return sweep
+        out["content_sweep"] = sweep_of(pnorm, ("race", "pan240x2", "pan240seq", "noise", "flat"))
+        if opt.config == "exh720":
+            out["content_sweep_mse"] = sweep_of(1, ("pan240x2", "noise"))
 
-    if proc >= 0 and world == 1 and not args.no_pcie:
+    if proc >= 0 and world == 1 and opt.pcie:
         # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields
         # come back (SURVEY.md §8(d) "end-to-end number including H2D/D2H")
         n_e2e = B
@@ -619,7 +763,7 @@ def main():
         out["sequence"] = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),
                            "mean_psnr_db": float(np.mean(rows[:, 6])),
                            "median_params": [float(x) for x in np.median(rows[:, :6], axis=0)]}
-    if world == 1 and not args.no_cpu_baseline and args.content == "synthetic":
+    if world == 1 and opt.cpu_baseline and opt.content == "synthetic":
         if proc == 0:
             cb = cpu_baseline_exhaustive(cfg)
             rows_c, ref_mf = cb.pop("rows_checked"), cb.pop("mf")
@@ -635,6 +779,7 @@ def main():
                 p0 = last["local_rows"][0, :6] if proc == -3 else last["params"][0]
                 ps0 = last["local_rows"][0, 6] if proc == -3 else last["psnr"][0]
                 cb["matches_gpu"] = bool(np.allclose(cb.pop("params"), p0, rtol=1e-10, atol=1e-12) and abs(cb.pop("psnr") - ps0) < 1e-9)
+        cb["host"] = host_description()
         out["cpu_baseline"] = cb
         if proc == 0:
             # BASELINE.md §3 "optimised CPU": the integer C oracle (gcc -O3, one core) on the same
@@ -647,7 +792,79 @@ def main():
             out["cpu_baseline_c"] = {"value": 1.0 / t_c, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                      "sample": "oracle/gme_oracle.c (integer C, gcc -O3) on the whole pair t=0,1 in %.2f s" % t_c,
                                      "matches_gpu": bool(np.array_equal(mf_c, seq.read_mv(0, 1)[0]))}
-    print(json.dumps(out), flush=True)
+    release()
+    return out
+
+
+def secondary_block(ctx, comm):
+    """The other BASELINE configs at a handful of steps each (same code path as `--config <name>`, fewer steps, a
+    smaller parity sample, no CPU baseline): the driver's one default run then carries configs[2] / configs[3] numbers."""
+    block = {}
+    t0 = time.perf_counter()
+    for name, pairs, steps, warmup, par_s in SECONDARY:
+        opt = types.SimpleNamespace(config=name, content="synthetic", pairs=pairs, steps=steps, warmup=warmup,
+                                    cpu_baseline=False, content_sweep=False, pcie=False, parity_budget_s=par_s)
+        t1 = time.perf_counter()
+        try:
+            d = measure(opt, ctx, comm, 0, 1)
+        except Exception as e:                      # noqa: BLE001 -- one config must not take the headline line down
+            block[name] = {"error": repr(e)}
+            continue
+        entry = {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                 "pairs_per_step": pairs, "steps": steps, "warmup": warmup, "streams": d["config"]["streams_per_gpu"],
+                 "kernel": d["roofline"]["kernel"], "kernel_ms_per_launch": d["roofline"]["kernel_ms_per_launch"],
+                 "hbm_frac_of_dominant_kernel": d["roofline"]["frac"],
+                 "parity_ok": d["parity"]["ok"], "pairs_checked_vs_c_oracle": d["parity"]["pairs_checked"],
+                 "seconds": round(time.perf_counter() - t1, 1)}
+        if "whole_step" in d["roofline"]:
+            entry["whole_step_hbm_frac"] = d["roofline"]["whole_step"]["frac"]
+        if "elimination" in d:
+            entry["surviving_fraction"] = d["elimination"]["surviving_fraction"]
+        block[name] = entry
+    block["seconds"] = round(time.perf_counter() - t0, 1)
+    return block
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="frame pairs resident and processed per step per GPU (default %d: launch ramps, tails and "
+                         "the host-side solves of the GME stages cost the same per step whatever the batch)" % DEFAULT_PAIRS)
+    ap.add_argument("--config", default="exh720", choices=sorted(CONFIGS))
+    ap.add_argument("--content", default="synthetic", choices=["synthetic", "race", "pan240seq", "pan240x2", "noise", "flat"],
+                    help="frame content of the exhaustive / walk configs (uploaded from the host unless synthetic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-content-sweep", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs the default line also times")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d does not match WORLD_SIZE=%d: launch it with torch.distributed.run "
+                 "--nproc-per-node %d (or plainly for --gpus 1)" % (args.gpus, world, args.gpus))
+    if CONFIGS[args.config][4] < 0 and args.content != "synthetic":
+        sys.exit("--content applies to the block-matching configs only")
+
+    import _gme_native as native
+    ndev = native.load_library().gme_device_count()
+    ctx = native.Context(local % max(ndev, 1))          # rehearsals may put several ranks on one card
+    comm = Comm(ctx, rank, world, local % max(ndev, 1))
+    opt = types.SimpleNamespace(config=args.config, content=args.content, pairs=args.pairs, steps=args.steps, warmup=args.warmup,
+                                cpu_baseline=not args.no_cpu_baseline, content_sweep=not args.no_content_sweep,
+                                pcie=not args.no_pcie, parity_budget_s=PARITY_BUDGET_S)
+    out = measure(opt, ctx, comm, rank, world)
+    if rank == 0:
+        default_command = (args.config == "exh720" and args.content == "synthetic" and world == 1 and args.pairs is None
+                           and comm.kind == "none")
+        if default_command and not args.no_secondary:
+            out["secondary"] = secondary_block(ctx, comm)
+        print(json.dumps(out), flush=True)
     comm.close()
 
 

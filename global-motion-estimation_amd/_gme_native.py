@@ -63,6 +63,10 @@ _SIGNATURES = {
     "gme_seq_bbme_streamed": (_i, [_vp, _c_u8p, _i, ctypes.c_int64, _i, _i, _i, _i, _i, _i, _i, _c_i32p]),
     "gme_host_alloc": (_vp, [ctypes.c_size_t]),
     "gme_host_free": (None, [_vp]),
+    "gme_comm_probe": (_i, []),
+    "gme_comm_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "gme_seq_mv_summary": (_i, [_vp, _c_f64p]),
+    "gme_seq_mv_summary_gather": (_i, [_vp, _i, _c_f64p]),
     "gme_comm_unique_id": (_i, [ctypes.c_char_p]),
     "gme_comm_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
     "gme_comm_destroy": (_i, [_vp]),
@@ -386,6 +390,22 @@ class Sequence:
         out = np.empty((count,) + self._mv_shape[1:], dtype=np.int32)
         if out.size:
             _check(self.lib.gme_seq_read_mv(self.handle, first, count, _p(out, _c_i32p)), self.lib)
+        return out
+
+    def mv_summary(self):
+        """Per-pair summary rows of the last bbme() field -> float64[P, 6] = modal vector x, y (over [-64, 64)^2),
+        its block count, sum of x, sum of y, checksum (include/gme_hip.h: gme_seq_mv_summary)."""
+        out = np.empty((self._mv_shape[0], 6), dtype=np.float64)
+        _check(self.lib.gme_seq_mv_summary(self.handle, _p(out, _c_f64p)), self.lib)
+        return out
+
+    def mv_summary_gather(self, n_max, world, slot=0):
+        """mv_summary() of every rank, all-gathered device to device over the context's RCCL communicator
+        -> float64[world, n_max, 6] (each rank's block zero-padded to n_max rows).  In split-phase mode the array
+        is filled once wait() returns; `slot` picks one of several page-locked result buffers so that a caller
+        can queue the next step while it still reads the previous one."""
+        out = self._buffer("gathered%d" % slot, (int(world), int(n_max), 6), np.float64)
+        _check(self.lib.gme_seq_mv_summary_gather(self.handle, int(n_max), _p(out, _c_f64p)), self.lib)
         return out
 
     # ---- GME stages

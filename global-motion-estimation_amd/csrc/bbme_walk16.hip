@@ -1,7 +1,7 @@
 // Walk searches (diamond, three-step, 2-D log) specialised for the two geometries the
 // global-motion pipeline runs all the time (motion.py:27-29,224-229):
 //
-//   k_walk16<PNORM, DIA>  bs = 16: one wavefront per macroblock, 8 blocks per wave one after the other (the
+//   k_walk16<PNORM> (diamond), k_walk16s<PNORM, PROC> (three-step, 2-D log)  bs = 16: one wavefront per macroblock, 8 blocks per wave one after the other (the
 //                     next block's anchors and first window are fetched while the current one is walked, two
 //                     register sets used in turn).  The wave is cut into 8 groups
 //                     of 8 lanes; a group evaluates one candidate per round, each lane owning
@@ -11,10 +11,12 @@
 //                     the group.  Up to 8 candidates cost one round; the centre of a pattern is
 //                     the previous winner, whose cost is carried instead of recomputed.  The window is
 //                     staged branch-free through a buffer resource (out-of-plane reads return 0).
-//                     DIA = true is the diamond search on its own (the GME levels 1-2): rounds pick
+//                     k_walk16 is the diamond search on its own (the GME levels 1-2): rounds pick
 //                     the winner in the vector unit (PATTERN_MIN), 41 vector + ~35 scalar instructions
-//                     per round of 8 candidates under MSE.  DIA = false: three-step and
-//                     2-D log, which keep wave-uniform candidate arrays (EVAL8).
+//                     per round of 8 candidates under MSE.  Three-step and 2-D log are instances of their own
+//                     (PROC): every group derives its candidate from its index, validity is a per-lane test, the
+//                     round's bounding box comes from the separable row / column validity (EVALV) and the winner
+//                     from the same DPP minimum -- no wave-uniform candidate arrays, no scalar spills.
 //   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
 //                     coarsest pyramid level, 5400 blocks per 720x480 pair).
 //
@@ -30,6 +32,7 @@ struct WalkDev {
     long long plane_stride;
     int pairs, H, W, pitch, sw, procedure;
     int nbr, nbc, bpw;
+    int st1, st2, st3;        // three-step: int((2 sw + bs) / 3), / 5, / 10 (bbme.py:211-213)
     int32_t* mf;
     int* status;
 };
@@ -221,6 +224,26 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
     return group_eval_at<PNORM>(a, aa, window_offset(sbase + lds_address(lds), rr, cc, lrow * (4 * WIN_PITCH)), (uint32_t)cc & 3u, valid);
 }
 
+// minimum of one key per 8-lane group (every lane of a group holds its group's key) -> wave-uniform: one DPP rotate
+// inside each 16-lane row, rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31),
+// lane 63 ends with the minimum
+__device__ __forceinline__ unsigned groups_min(unsigned key)
+{
+    key = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key, 0x128, 0xF, 0xF, false));   // row_ror 8
+    key = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key, 0x142, 0xA, 0xF, false));
+    key = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key, 0x143, 0xC, 0xF, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)key, 63);
+}
+
+// range of the valid ones among the three positions org - st, org, org + st of one axis (valid: 0 <= v <= limit);
+// lo > hi when none is
+__device__ __forceinline__ void axis_range3(int org, int st, int limit, int& lo, int& hi)
+{
+    const bool v0 = org - st >= 0 && org - st <= limit, v1 = org >= 0 && org <= limit, v2 = org + st >= 0 && org + st <= limit;
+    lo = v0 ? org - st : v1 ? org : v2 ? org + st : 1 << 30;
+    hi = v2 ? org + st : v1 ? org : v0 ? org - st : -(1 << 30);
+}
+
 // What a wave fetches ahead for a block: its 2 anchor rows per lane and, for the diamond search (whose first
 // window position depends on the block alone), the lane's share of that window.
 struct WalkPre {
@@ -256,11 +279,12 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
     }
 }
 
-// one 16x16 block of one frame pair, walked by one wave (DIA: the diamond search, else three-step or 2-D log)
-template <int PNORM, bool DIA>
+// one 16x16 block of one frame pair, walked by one wave; PROC = GME_SEARCH_THREESTEP / TWODLOG / DIAMOND
+template <int PNORM, int PROC>
 __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, const int blk, const int nblk, uint32_t* win,
                                            const WalkPre& pre)
 {
+    constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
     const long long gid = (long long)pair * nblk + blk;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const int lane = threadIdx.x & 63;
@@ -287,27 +311,25 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)(a[0] + a[7] + aa) >> 30; o[1] = 0; }
     return;
 #endif
-#define EVAL8(n, CR, CC, OK, COST)                                                                   \
+    // cost of this lane's group's candidate (RR, CC, OK: per-lane values, equal inside a group) -> COST in every lane of
+    // the group (INF32 if !OK).  [RMIN, RMAX] x [CMIN, CMAX] is the wave-uniform bounding box of the round's valid
+    // candidates (RMIN > RMAX: none): when it fits, the round is served from the LDS window, which is moved (centred on
+    // the box) if it does not cover it; a pattern wider than the window (first steps of three-step / 2-D log) reads
+    // global memory directly.
+#define EVALV(RR, CC, OK, RMIN, RMAX, CMIN, CMAX, COST)                                               \
     do {                                                                                             \
-        int rmin_ = 1 << 30, rmax_ = -(1 << 30), cmin_ = 1 << 30, cmax_ = -(1 << 30);                \
-        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (OK[k_]) {                             \
-            rmin_ = min(rmin_, CR[k_]); rmax_ = max(rmax_, CR[k_]);                                  \
-            cmin_ = min(cmin_, CC[k_]); cmax_ = max(cmax_, CC[k_]); }                                \
-        bool lds_ok_ = rmax_ >= rmin_;                                                               \
-        if (lds_ok_ && !(have_win && rmin_ >= wr0 && rmax_ <= wr0 + WIN_ROWS - 16 && cmin_ >= wc0 && \
-                         cmax_ <= wc0 + WIN_SPAN)) {                                                 \
-            if (rmax_ - rmin_ <= WIN_ROWS - 16 && cmax_ - cmin_ <= WIN_SPAN - 3) {                   \
-                wr0 = rmin_ - (WIN_ROWS - 16 - (rmax_ - rmin_)) / 2;                                 \
-                wc0 = max(0, (cmin_ - (WIN_SPAN - 3 - (cmax_ - cmin_)) / 2) & ~3);                   \
+        bool lds_ok_ = (RMAX) >= (RMIN) && (CMAX) >= (CMIN);                                         \
+        if (lds_ok_ && !(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 && \
+                         (CMAX) <= wc0 + WIN_SPAN)) {                                                \
+            if ((RMAX) - (RMIN) <= WIN_ROWS - 16 && (CMAX) - (CMIN) <= WIN_SPAN - 3) {               \
+                wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                              \
+                wc0 = max(0, ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3);                \
                 stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                               \
                 have_win = true;                                                                     \
             } else lds_ok_ = false;                                                                  \
         }                                                                                            \
-        int rr_ = 0, cc_ = 0; bool ok_ = false;                                                      \
-        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) if (grp == k_) { rr_ = CR[k_]; cc_ = CC[k_]; ok_ = OK[k_]; } \
-        const unsigned c_ = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, -wr0 * (4 * WIN_PITCH) - wc0, rr_, cc_, ok_, lrow)  \
-                                    : group_eval<PNORM>(a, aa, cur, pitch, rr_, cc_, ok_, lrow);     \
-        _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) COST[k_] = __builtin_amdgcn_readlane((int)c_, k_ * 8); \
+        COST = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, -wr0 * (4 * WIN_PITCH) - wc0, RR, CC, OK, lrow)  \
+                       : group_eval<PNORM>(a, aa, cur, pitch, RR, CC, OK, lrow);                     \
     } while (0)
 
     int out0 = 0, out1 = 0;
@@ -359,12 +381,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 #define PATTERN_MIN(n, OFF, SH, KMIN)                                                                  \
     do {                                                                                             \
         const unsigned c_ = group_eval_at<PNORM>(a, aa, OFF, SH, grp < (n));                        \
-        unsigned key_ = grp < (n) ? (c_ << 3) | (unsigned)grp : INF32;                               \
-        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x128, 0xF, 0xF, false)); /* row_ror 8 */ \
-        /* rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31): lane 63 ends with the minimum */ \
-        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x142, 0xA, 0xF, false)); \
-        key_ = min(key_, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key_, 0x143, 0xC, 0xF, false)); \
-        KMIN = (unsigned)__builtin_amdgcn_readlane((int)key_, 63);                                   \
+        KMIN = groups_min(grp < (n) ? (c_ << 3) | (unsigned)grp : INF32);                            \
     } while (0)
         {   // first centre: clamp(origin) (bbme.py:498-506), evaluated once, by all 64 lanes together: lane l takes
             // dword l % 4 of block row l / 4 (two window dwords, one v_alignbyte with a scalar shift, one v_sad_u8 or
@@ -440,67 +457,83 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 #undef PATTERN_MIN
 #undef RESTAGE_IF_OUTSIDE
 #undef WINDOW_RANGES
-    } else if (d.procedure == GME_SEARCH_THREESTEP) {
-        const int n = 2 * d.sw + 16;
-        const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };
+    } else if (PROC == GME_SEARCH_THREESTEP) {
+        // bbme.py:182-341.  Candidate k = 0..8 of a step st around (org_r, org_c): column offset (k / 3 - 1) st in the outer
+        // loop, row offset (k % 3 - 1) st in the inner one; out-of-frame candidates are skipped, the first strict
+        // minimum wins.  Group g evaluates candidate g, candidate 8 takes a second round in group 0.
+        const int ur = grp % 3 - 1, uc = grp / 3 - 1;              // this group's offset in units of the step
         int drow = 0, dcol = 0, trow = 0, tcol = 0, org_r = r0, org_c = c0;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int st = steps[s];
-            // scan order: column offset outer, row offset inner, each over (-st, 0, st)
-            int cr[9], cc[9], wr[9], wc[9]; bool ok[9]; unsigned cost[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                wc[k] = (k / 3 - 1) * st; wr[k] = (k % 3 - 1) * st;
-                cr[k] = org_r + wr[k]; cc[k] = org_c + wc[k];
-                ok[k] = cr[k] >= 0 && cc[k] >= 0 && cr[k] + 16 <= H && cc[k] + 16 <= W;
-            }
-            EVAL8(8, cr, cc, ok, cost);
+            const int st = s == 0 ? d.st1 : s == 1 ? d.st2 : d.st3;
+            int rmin, rmax, cmin, cmax;
+            axis_range3(org_r, st, H - 16, rmin, rmax);
+            axis_range3(org_c, st, W - 16, cmin, cmax);
+            unsigned key;
             {
-                int cr1[1] = { cr[8] }, cc1[1] = { cc[8] }; bool ok1[1] = { ok[8] }; unsigned c1[1];
-                EVAL8(1, cr1, cc1, ok1, c1);
-                cost[8] = c1[0];
+                const int rr = org_r + ur * st, cc = org_c + uc * st;
+                const bool ok = rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                unsigned c;
+                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+                key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
-            unsigned best = INF32;
-            int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) if (ok[k] && cost[k] < best) { best = cost[k]; kr = wr[k]; kc = wc[k]; }
+            {
+                const int rr = org_r + st, cc = org_c + st;        // candidate 8 (wave-uniform), by group 0
+                const bool ok = grp == 0 && rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                unsigned c;
+                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+                key = min(key, ok ? (c << 4) | 8u : INF32);
+            }
+            const unsigned kmin = groups_min(key);
+            int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;       // nothing valid: the stale offsets stay (bbme.py:332-336)
+            if (kmin != INF32) {
+                const int k = (int)(kmin & 15u);
+                kr = (k % 3 - 1) * st; kc = (k / 3 - 1) * st;
+            }
             if (s == 0) { drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol; }
             else { trow = kr; tcol = kc; drow += trow; dcol += tcol; org_r += drow; org_c += dcol; }
         }
         out0 = dcol; out1 = drow;
-    } else {   // 2-D log
+    } else {   // 2-D log, bbme.py:344-433
+        // step > 2: centre, (+s, 0), (-s, 0), (0, +s), (0, -s) as (row, col) offsets, groups 0..4; step == 2: the ring
+        // (k / 3 - 1, k % 3 - 1) * 2 for k = 0..8, candidate 8 in a second round of group 0
+        const int xr = grp == 1 ? 1 : grp == 2 ? -1 : 0;
+        const int xc = grp == 3 ? 1 : grp == 4 ? -1 : 0;
+        const int gr = grp / 3 - 1, gc = grp % 3 - 1;
         int br = 0, bc = 0, pr = r0, pc = c0, step = d.sw, it = 0;
         while (step > 1) {
-            int cr[9], cc[9]; bool ok[9]; unsigned cost[9];
             const bool cross = step > 2;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                if (cross) {
-                    cr[k] = pr + (k == 1 ? step : k == 2 ? -step : 0);
-                    cc[k] = pc + (k == 3 ? step : k == 4 ? -step : 0);
-                    ok[k] = k < 5;
-                } else {
-                    cr[k] = pr + (k / 3 - 1) * 2; cc[k] = pc + (k % 3 - 1) * 2; ok[k] = true;
-                }
-                ok[k] = ok[k] && cr[k] >= 0 && cc[k] >= 0 && cr[k] + 16 <= H && cc[k] + 16 <= W;
-            }
-            EVAL8(8, cr, cc, ok, cost);
+            int rmin, rmax, cmin, cmax;
+            axis_range3(pr, cross ? step : 2, H - 16, rmin, rmax);
+            axis_range3(pc, cross ? step : 2, W - 16, cmin, cmax);
+            unsigned key;
             {
-                int cr1[1] = { cr[8] }, cc1[1] = { cc[8] }; bool ok1[1] = { ok[8] }; unsigned c1[1];
-                EVAL8(1, cr1, cc1, ok1, c1);
-                cost[8] = c1[0];
+                const int rr = pr + (cross ? xr * step : gr * 2), cc = pc + (cross ? xc * step : gc * 2);
+                const bool ok = (!cross || grp < 5) && rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                unsigned c;
+                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+                key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
-            unsigned best = INF32;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) if (ok[k] && cost[k] < best) { best = cost[k]; br = cr[k]; bc = cc[k]; }
+            if (!cross) {
+                const int rr = pr + 2, cc = pc + 2;
+                const bool ok = grp == 0 && rr <= H - 16 && cc <= W - 16;        // pr, pc >= 0
+                unsigned c;
+                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+                key = min(key, ok ? (c << 4) | 8u : INF32);
+            }
+            const unsigned kmin = groups_min(key);
+            if (kmin != INF32) {                                    // the centre is always valid, so this always holds
+                const int k = (int)(kmin & 15u);
+                if (cross) { br = pr + (k == 1 ? step : k == 2 ? -step : 0); bc = pc + (k == 3 ? step : k == 4 ? -step : 0); }
+                else { br = pr + (k / 3 - 1) * 2; bc = pc + (k % 3 - 1) * 2; }
+            }
             if ((br == pr && bc == pc) || step == 2) step /= 2;
             pr = br; pc = bc;
             if (++it > cap) { overrun = true; break; }
         }
         out1 = br - r0; out0 = bc - c0;
     }
-#undef EVAL8
+#undef EVALV
     if (lane == 0) {
         if (overrun) atomicExch(d.status, 1);
         int32_t* o = d.mf + gid * 2;
@@ -510,10 +543,10 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 
 // Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
 // dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
-template <int PNORM, bool DIA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_walk16(WalkDev d)
+template <int PNORM, int PROC>
+__device__ __forceinline__ void walk16_workgroup(const WalkDev& d, uint32_t (&win_all)[4][WIN_ALLOC])
 {
-    __shared__ uint32_t win_all[4][WIN_ALLOC];
+    constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nblk = d.nbr * d.nbc;
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b serves pair
@@ -530,13 +563,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int blk = base + 4 * i;                               // valid: checked before it was fetched
         const bool more1 = i + 1 < d.bpw && blk + 4 < nblk;
         if (more1) walk_prefetch<DIA>(pb, d, pair, blk + 4);         // in flight during this block's walk
-        walk_block<PNORM, DIA>(d, pair, blk, nblk, win_all[wave_in_wg], pa);
+        walk_block<PNORM, PROC>(d, pair, blk, nblk, win_all[wave_in_wg], pa);
         if (!more1) break;
         const bool more2 = i + 2 < d.bpw && blk + 8 < nblk;
         if (more2) walk_prefetch<DIA>(pa, d, pair, blk + 8);
-        walk_block<PNORM, DIA>(d, pair, blk + 4, nblk, win_all[wave_in_wg], pb);
+        walk_block<PNORM, PROC>(d, pair, blk + 4, nblk, win_all[wave_in_wg], pb);
         if (!more2) break;
     }
+}
+
+// The diamond instance is held to 64 VGPRs (8 waves per SIMD cover its LDS -> dot4 -> DPP -> v_readlane -> scalar chain);
+// three-step and 2-D log fit 8 waves anyway, and without the cap their scalar state needs no spill (81 / 78 SGPRs).
+template <int PNORM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_walk16(WalkDev d)
+{
+    __shared__ uint32_t win_all[4][WIN_ALLOC];
+    walk16_workgroup<PNORM, GME_SEARCH_DIAMOND>(d, win_all);
+}
+
+template <int PNORM, int PROC>
+__global__ void __launch_bounds__(256) k_walk16s(WalkDev d)
+{
+    __shared__ uint32_t win_all[4][WIN_ALLOC];
+    walk16_workgroup<PNORM, PROC>(d, win_all);
 }
 
 // ---------------------------------------------------------------------------
@@ -610,6 +659,8 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     d.prev = job.prev; d.cur = job.cur; d.plane_stride = job.plane_stride; d.pairs = job.pairs;
     d.H = job.H; d.W = job.W; d.pitch = job.pitch; d.sw = job.sw; d.procedure = job.procedure;
     d.nbr = nbr; d.nbc = nbc; d.mf = job.mf; d.status = ctx->status;
+    const int span = 2 * job.sw + job.bs;
+    d.st1 = (int)(span / 3.0); d.st2 = (int)(span / 5.0); d.st3 = (int)(span / 10.0);
     const long long total = (long long)nbr * nbc * job.pairs;
     if (job.bs == 16) {
         static const int bpw_env = getenv("GME_WALK_BPW") ? atoi(getenv("GME_WALK_BPW")) : 0;
@@ -618,12 +669,19 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         const long long groups = (long long)((job.pairs + 7) / 8) * 8 * wpp;
         GME_REQUIRE(groups < (1ll << 31), GME_ERR_ARG, "too many workgroups in one launch");
         const unsigned grid = (unsigned)groups;
-        plan_note(ctx, 0, "k_walk16<%d,%s> grid %u blocks/wave %d", job.pnorm, job.procedure == GME_SEARCH_DIAMOND ? "diamond" : "steps", (unsigned)grid, d.bpw);
-        const bool dia = job.procedure == GME_SEARCH_DIAMOND;     // its own instance: half the scalar state of the other two
-        if (job.pnorm == 0 && dia) hipLaunchKernelGGL((k_walk16<0, true>), dim3(grid), dim3(256), 0, ctx->stream, d);
-        else if (job.pnorm == 0) hipLaunchKernelGGL((k_walk16<0, false>), dim3(grid), dim3(256), 0, ctx->stream, d);
-        else if (dia) hipLaunchKernelGGL((k_walk16<1, true>), dim3(grid), dim3(256), 0, ctx->stream, d);
-        else hipLaunchKernelGGL((k_walk16<1, false>), dim3(grid), dim3(256), 0, ctx->stream, d);
+        // one instance per search and norm: the diamond alone needs half the scalar state of a body that holds all three
+        if (job.procedure == GME_SEARCH_DIAMOND) {
+            plan_note(ctx, 0, "k_walk16<%d> (diamond) grid %u blocks/wave %d", job.pnorm, (unsigned)grid, d.bpw);
+            if (job.pnorm == 0) hipLaunchKernelGGL(k_walk16<0>, dim3(grid), dim3(256), 0, ctx->stream, d);
+            else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
+        } else {
+            const bool tss = job.procedure == GME_SEARCH_THREESTEP;
+            plan_note(ctx, 0, "k_walk16s<%d,%d> (%s) grid %u blocks/wave %d", job.pnorm, job.procedure, tss ? "three-step" : "2-D log", (unsigned)grid, d.bpw);
+            if (tss && job.pnorm == 0) hipLaunchKernelGGL((k_walk16s<0, GME_SEARCH_THREESTEP>), dim3(grid), dim3(256), 0, ctx->stream, d);
+            else if (tss) hipLaunchKernelGGL((k_walk16s<1, GME_SEARCH_THREESTEP>), dim3(grid), dim3(256), 0, ctx->stream, d);
+            else if (job.pnorm == 0) hipLaunchKernelGGL((k_walk16s<0, GME_SEARCH_TWODLOG>), dim3(grid), dim3(256), 0, ctx->stream, d);
+            else hipLaunchKernelGGL((k_walk16s<1, GME_SEARCH_TWODLOG>), dim3(grid), dim3(256), 0, ctx->stream, d);
+        }
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
         const unsigned grid = (unsigned)((total + 255) / 256);
         plan_note(ctx, 0, "k_dense2<%d> grid %u", job.pnorm, (unsigned)grid);

@@ -427,6 +427,8 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     if (s->sse) hipFree(s->sse);
     if (s->comp_params) hipFree(s->comp_params);
     if (s->synth_canvas) hipFree(s->synth_canvas);
+    if (s->summary) hipFree(s->summary);
+    if (s->gathered) hipFree(s->gathered);
     if (s->ready) hipEventDestroy(s->ready);
     delete s;
 }
@@ -701,6 +703,8 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
     STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream, gate, 0));
     STREAM_TRY(hipStreamWaitEvent(ctx->back_stream, gate, 0));
     int p_done = 0;                                            // pairs searched so far
+    int tab_done = 0;                                          // frames whose auxiliary table rows exist (always from frame 0:
+                                                               // a later call with a smaller frame distance reads them as `cur`)
     int back_first = 0, back_count = 0, back_chunk = -1;       // fields of the previous chunk, still to be read back
     auto read_back = [&]() -> bool {
         if (back_count == 0) return true;
@@ -758,9 +762,10 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
             job.mf = s->mv + per * p_done; job.sqbox_cur = nullptr; job.sqbox_stride = 0;
             job.chained = p_done > 0;
             if (aux) {
-                // box sums of squares of the `cur` frames this chunk is the first to use
-                const int t0 = p_done + fd;                    // == the previous chunk's end, or fd for the first pairs
+                // box sums of squares of every frame uploaded since the last table launch
+                const int t0 = tab_done;
                 rc = launch_aux_table(ctx, aux, p.at(t0), p.stride, f1 - t0, p.H, p.W, p.pitch, s->sqbox[2] + (size_t)t0 * p.stride, p.stride);
+                tab_done = f1;
                 if (rc == GME_OK) { job.sqbox_cur = s->sqbox[2] + (size_t)(p_done + fd) * p.stride; job.sqbox_stride = p.stride; }
             }
             if (rc == GME_OK) rc = launch_bbme(ctx, job);
@@ -780,7 +785,7 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
     if (ctx->copy_stream2 && hipStreamSynchronize(ctx->copy_stream2) != hipSuccess) e1 = hipErrorUnknown;
     rc = ctx_finish(ctx);
     cleanup();
-    if (aux) { s->sqbox_valid[2] = (count == s->N); s->sqbox_kind[2] = aux; }
+    if (aux) { s->sqbox_valid[2] = (count == s->N && tab_done == count); s->sqbox_kind[2] = aux; }
     if (e1 != hipSuccess || e2 != hipSuccess) { gme_set_error("gme_seq_bbme_streamed: copy stream failed"); return GME_ERR_HIP; }
     return rc;
 }

@@ -20,6 +20,7 @@ typedef int (*fn_destroy)(void* comm);
 typedef int (*fn_allgather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream);
 typedef int (*fn_allreduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_comm_int)(void* comm, int* out);
 constexpr int kFloat64 = 8, kMax = 2;      // ncclFloat64, ncclMax
 
 struct Rccl {
@@ -30,6 +31,7 @@ struct Rccl {
     fn_allgather allgather = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_errstr errstr = nullptr;
+    fn_comm_int count = nullptr, user_rank = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -50,7 +52,10 @@ int rccl_load()
     r.allgather = (fn_allgather)dlsym(so, "ncclAllGather");
     r.allreduce = (fn_allreduce)dlsym(so, "ncclAllReduce");
     r.errstr = (fn_errstr)dlsym(so, "ncclGetErrorString");
-    GME_REQUIRE(r.get_id && r.init_rank && r.destroy && r.allgather && r.allreduce, GME_ERR_HIP, "librccl.so lacks a symbol");
+    r.count = (fn_comm_int)dlsym(so, "ncclCommCount");
+    r.user_rank = (fn_comm_int)dlsym(so, "ncclCommUserRank");
+    GME_REQUIRE(r.get_id && r.init_rank && r.destroy && r.allgather && r.allreduce && r.count && r.user_rank, GME_ERR_HIP,
+                "librccl.so lacks a symbol");
     g_rccl = r;
     return GME_OK;
 }
@@ -65,6 +70,8 @@ int rccl_load()
     } while (0)
 
 }  // namespace
+
+extern "C" int gme_comm_probe(void) { return rccl_load(); }
 
 extern "C" int gme_comm_unique_id(char id_out[128])
 {
@@ -142,6 +149,85 @@ extern "C" int gme_comm_allreduce_max(gme_ctx* ctx, double* v, int n)
     GME_HIP_TRY(hipMemcpyAsync(base, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     GME_RCCL_TRY(g_rccl.allreduce(base, base, (size_t)n, kFloat64, kMax, ctx->comm, ctx->stream));
     GME_HIP_TRY(hipMemcpyAsync(v, base, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GME_OK;
+}
+
+// what RCCL itself says about the communicator (ncclCommUserRank / ncclCommCount), not what the caller passed in
+extern "C" int gme_comm_info(gme_ctx* ctx, int* rank_out, int* world_out)
+{
+    GME_REQUIRE(ctx != nullptr, GME_ERR_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GME_REQUIRE(ctx->comm != nullptr, GME_ERR_STATE, "gme_comm_info before gme_comm_init");
+    int r = -1, n = -1;
+    GME_RCCL_TRY(g_rccl.user_rank(ctx->comm, &r));
+    GME_RCCL_TRY(g_rccl.count(ctx->comm, &n));
+    if (rank_out) *rank_out = r;
+    if (world_out) *world_out = n;
+    return GME_OK;
+}
+
+// ---- per-pair summary rows of the last block-matching field, and their exchange ---------------------------------
+static int grow(double** ptr, size_t* have, size_t want)
+{
+    if (*ptr && *have >= want) return GME_OK;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr; *have = 0;
+    if (hipMalloc((void**)ptr, want) != hipSuccess) { gme_set_error("out of device memory (%zu bytes of summary rows)", want); return GME_ERR_NOMEM; }
+    *have = want;
+    return GME_OK;
+}
+
+static int summary_rows(gme_seq* s, int n_max)
+{
+    gme_ctx* ctx = s->ctx;
+    GME_REQUIRE(s->mv != nullptr && s->mv_pairs > 0, GME_ERR_STATE, "no motion field yet: call gme_seq_bbme first");
+    GME_REQUIRE(n_max >= s->mv_pairs, GME_ERR_ARG, "%d rows do not hold the %d pairs of this sequence", n_max, s->mv_pairs);
+    const size_t bytes = (size_t)n_max * 6 * sizeof(double);
+    if (!s->summary || s->summary_bytes < bytes) {
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));        // an earlier gather may still read the old rows
+        int rc = grow(&s->summary, &s->summary_bytes, bytes);
+        if (rc) return rc;
+    }
+    if (n_max > s->mv_pairs)                                   // the padding other ranks receive
+        GME_HIP_TRY(hipMemsetAsync(s->summary + (size_t)s->mv_pairs * 6, 0, (size_t)(n_max - s->mv_pairs) * 6 * sizeof(double), ctx->stream));
+    return launch_mv_summary(ctx, s->mv, s->mv_pairs, s->mv_h * s->mv_w, s->summary);
+}
+
+extern "C" int gme_seq_mv_summary(gme_seq* s, double* rows_out)
+{
+    GME_REQUIRE(s != nullptr && rows_out != nullptr, GME_ERR_ARG, "gme_seq_mv_summary: null pointer");
+    gme_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GME_HIP_TRY(hipSetDevice(ctx->device));
+    int rc = summary_rows(s, s->mv_pairs);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpyAsync(rows_out, s->summary, (size_t)s->mv_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GME_OK;
+}
+
+// The rows never visit the host on the way: summary kernel -> ncclAllGather of the device rows (xGMI) -> one copy of
+// the gathered block into `out`.  In split-phase mode (gme_seq_set_split_phase) the call returns once that copy is
+// queued and gme_seq_wait delivers it, so the next step's search runs behind the collective without a gap.
+extern "C" int gme_seq_mv_summary_gather(gme_seq* s, int n_max, double* out)
+{
+    GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_mv_summary_gather: null pointer");
+    gme_ctx* ctx = s->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GME_HIP_TRY(hipSetDevice(ctx->device));
+    GME_REQUIRE(ctx->comm != nullptr, GME_ERR_STATE, "gme_seq_mv_summary_gather before gme_comm_init");
+    int rc = summary_rows(s, n_max);
+    if (rc) return rc;
+    const size_t block = (size_t)n_max * 6, bytes = block * sizeof(double) * (size_t)ctx->comm_world;
+    if (!s->gathered || s->gathered_bytes < bytes) {
+        GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        rc = grow(&s->gathered, &s->gathered_bytes, bytes);
+        if (rc) return rc;
+    }
+    GME_RCCL_TRY(g_rccl.allgather(s->summary, s->gathered, block, kFloat64, ctx->comm, ctx->stream));
+    GME_HIP_TRY(hipMemcpyAsync(out, s->gathered, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (s->split_phase) { GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream)); return GME_OK; }
     GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return GME_OK;
 }

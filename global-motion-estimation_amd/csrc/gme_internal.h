@@ -116,6 +116,11 @@ struct gme_seq {
     Plane comp;                   // [P] compensated frames
     double* comp_params = nullptr;       // [P][6]
     unsigned long long* sse = nullptr;   // [P]
+    // per-pair summary rows of `mv` (gme_seq_mv_summary) and their all-gather over the ranks (gme_seq_mv_summary_gather)
+    double* summary = nullptr;           // [n_max][6], zero-padded behind mv_pairs rows
+    size_t summary_bytes = 0;
+    double* gathered = nullptr;          // [world][n_max][6]
+    size_t gathered_bytes = 0;
     uint8_t* synth_canvas = nullptr;
     uint64_t synth_seed = 0;
     bool synth_valid = false;
@@ -158,6 +163,7 @@ int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, c
                      int drop_count, int level_H, int level_W, int16_t* model, uint8_t* mask,
                      int32_t* diff, int32_t* thr, double* sums, void* list);
 int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out);
+int launch_mv_summary(gme_ctx* ctx, const int32_t* mf, int pairs, int n_blocks, double* rows);
 int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride, int pairs, int H,
                       int W, int pitch, const int32_t* mf32, const double* params, int h, int w,
                       uint8_t* out, int64_t out_stride, int out_pitch, const uint8_t* cur,

@@ -181,6 +181,58 @@ __global__ void __launch_bounds__(256) k_first_params(const int32_t* dense, int 
 }
 
 // ---------------------------------------------------------------------------
+// Per-pair summary row of a motion field -- what a sharded block-matching run exchanges instead of the
+// fields themselves (gme_seq_mv_summary[_gather]): float64[6] =
+//   modal vector (x, y), the number of blocks that chose it, sum of x, sum of y, checksum.
+// The mode is taken over the vectors inside [-64, 64)^2 (both BASELINE windows: bbme.py:146-149 spans
+// [-sw, sw + bs)); ties go to the smaller (x + 64) * 128 + (y + 64).  The checksum is
+// sum_i ((i mod 251) + 1) * (3 x_i + 5 y_i) over the blocks in row-major order: integer, order-free.
+// ---------------------------------------------------------------------------
+constexpr int SUMMARY_HALF = 64, SUMMARY_SIDE = 2 * SUMMARY_HALF, SUMMARY_BINS = SUMMARY_SIDE * SUMMARY_SIDE;
+
+__global__ void __launch_bounds__(256) k_mv_summary(const int32_t* mf_all, int n, double* rows)
+{
+    extern __shared__ unsigned int hist[];                 // SUMMARY_BINS counters
+    __shared__ long long acc[3];
+    __shared__ unsigned long long best;
+    const int32_t* mf = mf_all + (long long)blockIdx.x * n * 2;
+    for (int b = threadIdx.x; b < SUMMARY_BINS; b += 256) hist[b] = 0;
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    long long sx = 0, sy = 0, ck = 0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int x = mf[2 * k], y = mf[2 * k + 1];
+        sx += x; sy += y;
+        ck += (long long)(k % 251 + 1) * (3 * (long long)x + 5 * (long long)y);
+        if (x >= -SUMMARY_HALF && x < SUMMARY_HALF && y >= -SUMMARY_HALF && y < SUMMARY_HALF)
+            atomicAdd(&hist[(x + SUMMARY_HALF) * SUMMARY_SIDE + (y + SUMMARY_HALF)], 1u);
+    }
+    atomicAdd((unsigned long long*)&acc[0], (unsigned long long)sx);
+    atomicAdd((unsigned long long*)&acc[1], (unsigned long long)sy);
+    atomicAdd((unsigned long long*)&acc[2], (unsigned long long)ck);
+    __syncthreads();
+    unsigned long long key = 0;                            // count << 16 | (0xFFFF - bin): larger count, then smaller bin
+    for (int b = threadIdx.x; b < SUMMARY_BINS; b += 256) {
+        const unsigned long long kb = ((unsigned long long)hist[b] << 16) | (unsigned)(0xFFFF - b);
+        if (hist[b] && kb > key) key = kb;
+    }
+    if (key) atomicMax(&best, key);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = rows + (long long)blockIdx.x * 6;
+        const unsigned long long kb = best;
+        const int bin = 0xFFFF - (int)(kb & 0xFFFF);
+        o[0] = kb ? (double)(bin / SUMMARY_SIDE - SUMMARY_HALF) : 0.0;
+        o[1] = kb ? (double)(bin % SUMMARY_SIDE - SUMMARY_HALF) : 0.0;
+        o[2] = (double)(kb >> 16);
+        o[3] = (double)acc[0];
+        o[4] = (double)acc[1];
+        o[5] = (double)acc[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // motion.affine_model / get_motion_field_affine (motion.py:91-105,139-157)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int16_t model_component(double p0, double p1, double p2, int i, int j)
@@ -644,6 +696,14 @@ int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blo
 {
     if (pairs == 0) return GME_OK;
     hipLaunchKernelGGL(k_first_params, dim3(pairs), dim3(256), 0, ctx->stream, dense, n_blocks, params0);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_mv_summary(gme_ctx* ctx, const int32_t* mf, int pairs, int n_blocks, double* rows)
+{
+    if (pairs == 0) return GME_OK;
+    hipLaunchKernelGGL(k_mv_summary, dim3(pairs), dim3(256), SUMMARY_BINS * sizeof(unsigned int), ctx->stream, mf, n_blocks, rows);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }

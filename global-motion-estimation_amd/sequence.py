@@ -9,8 +9,13 @@ only parallel axis the path has, so:
 * across GPUs (one process per GPU) contiguous pair ranges are dealt to the ranks, each
   rank needs its pairs' frames plus ``fd`` halo frames, and the only exchange is one
   all-gather of the per-pair ``float64[6]`` parameter vectors (48 B per pair) at the end
-  -- RCCL over xGMI when the process group is ``nccl``, ``gloo`` in the CPU tests.
+  -- RCCL over xGMI through the library's own communicator (gme_comm_*, gme_shard_gather).
 """
+import ctypes
+import os
+import stat
+import time
+
 import numpy as np
 
 import _gme_native as _native
@@ -32,94 +37,200 @@ def shard_frames(n_pairs, frame_distance, rank, world):
     return start, (stop - start) + frame_distance
 
 
-def gather_parameters(local, n_pairs, rank, world, device=None):
-    """All-gather per-pair parameter rows across ranks -> float64[n_pairs, k] on every rank.
-
-    Uses torch.distributed when a process group is initialised (backend nccl = RCCL on
-    ROCm: tensors are staged on ``device``; gloo: CPU tensors); with world == 1 it is
-    the identity.  Rows are padded to the largest shard so one fixed-size collective
-    serves ragged shards.
-    """
-    local = np.ascontiguousarray(local, dtype=np.float64)
-    if world == 1:
-        return local
-    import torch
-    import torch.distributed as dist
-    k = local.shape[1] if local.ndim == 2 else 6
-    longest, sizes = pad_and_trim(n_pairs, world)
-    buf = torch.zeros((longest, k), dtype=torch.float64)
-    if len(local):
-        buf[:len(local)] = torch.from_numpy(local)
-    if device is not None:
-        buf = buf.to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    rows = [o.cpu().numpy()[:b - a] for o, (a, b) in zip(out, sizes)]
-    return np.concatenate(rows, axis=0)
-
-
 # ---- the library's own RCCL communicator (gme_comm_*, include/gme_hip.h): no torch involved -------------
-def _id_file():
-    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of this node.  All ranks of one
-    launch share their parent (torch.distributed.run's agent, or the test's spawner), so its pid keeps
-    a stale file of an earlier launch on the same port from ever being read."""
-    import os
-    return os.environ.get("GME_COMM_ID_FILE") or "/tmp/gme_rccl_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+class CommUnavailable(RuntimeError):
+    """Raised by comm_init on EVERY rank of the launch when at least one rank cannot bring the RCCL
+    communicator up (no librccl, no id, ncclCommInitRank failed): the ranks can then take the same
+    fallback, or all exit; none is left waiting inside a collective."""
 
 
-def comm_exchange_id(make_id, rank, world, timeout_s=180.0):
-    """Rank 0 calls make_id() -> bytes and publishes them; every rank returns the same bytes."""
-    import os
-    import time
-    path = _id_file()
-    def publish(blob):
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
+def _process_start_time():
+    """Wall-clock time this process was started (the ranks of one launch start within a second or so of
+    each other; files older than that belong to an earlier launch)."""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: starttime in clock ticks since boot
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - (up - ticks / os.sysconf("SC_CLK_TCK"))
+    except Exception:                                                      # noqa: BLE001
+        return _IMPORT_TIME
+
+
+_IMPORT_TIME = time.time()
+_STALE_SLACK_S = 5.0
+
+
+def _rendezvous_base():
+    """Path prefix of this launch's rendezvous files.  GME_COMM_ID_FILE names it outright; otherwise it lives in
+    a directory only this user can enter (0700, checked) and is keyed by MASTER_PORT and the pid of the ranks'
+    common parent (torch.distributed.run's agent, or the test's spawner)."""
+    explicit = os.environ.get("GME_COMM_ID_FILE")
+    if explicit:
+        return explicit
+    d = os.path.join(os.environ.get("GME_COMM_DIR", "/tmp"), "gme_rccl_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("%s is not a private directory of uid %d (mode %o, owner %d)" % (d, os.getuid(), st.st_mode & 0o7777, st.st_uid))
+    return os.path.join(d, "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+
+
+class Rendezvous:
+    """File-based exchange of small blobs between the ranks of one launch on one node: publish(key, blob) writes
+    <base>.<key>.<rank> atomically (0600, O_EXCL | O_NOFOLLOW); collect(key) returns every rank's blob once all are
+    there.  A file is accepted only if it is a regular file of this user and not older than this process (minus a few
+    seconds of start-up skew): what an earlier launch with the same port and parent left behind is never read."""
+
+    def __init__(self, rank, world, timeout_s=180.0, base=None):
+        self.rank, self.world, self.timeout_s = int(rank), int(world), float(timeout_s)
+        self.base = base or _rendezvous_base()
+        self.not_before = _process_start_time() - _STALE_SLACK_S
+        self._mine = []
+
+    def _path(self, key, rank):
+        return "%s.%s.%d" % (self.base, key, rank)
+
+    def publish(self, key, blob):
+        path = self._path(key, self.rank)
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        for stale in (tmp, path):
+            try:
+                os.unlink(stale)
+            except FileNotFoundError:
+                pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(blob)
         os.replace(tmp, path)                    # atomic: readers see nothing or everything
+        self._mine.append(path)
 
+    def _read(self, key, rank):
+        try:
+            fd = os.open(self._path(key, rank), os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+        except (FileNotFoundError, OSError):
+            return None
+        with os.fdopen(fd, "rb") as f:
+            st = os.fstat(f.fileno())
+            if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_mtime < self.not_before:
+                return None
+            return f.read()
+
+    def collect(self, key, ranks=None):
+        ranks = list(range(self.world)) if ranks is None else list(ranks)
+        got, t0 = {}, time.time()
+        while True:
+            for r in ranks:
+                if r not in got:
+                    blob = self._read(key, r)
+                    if blob is not None:
+                        got[r] = blob
+            if len(got) == len(ranks):
+                return [got[r] for r in ranks]
+            if time.time() - t0 > self.timeout_s:
+                missing = [r for r in ranks if r not in got]
+                raise TimeoutError("rank %d: no '%s' from rank(s) %s at %s.* after %.0f s" % (self.rank, key, missing, self.base, self.timeout_s))
+            time.sleep(0.01)
+
+    def agree(self, key, ok, payload=b""):
+        """Every rank says ok / not ok (with a payload or a reason); returns all payloads if every rank was ok,
+        raises CommUnavailable on EVERY rank otherwise."""
+        self.publish(key, (b"ok:" if ok else b"no:") + payload)
+        blobs = self.collect(key)
+        bad = ["rank %d: %s" % (r, b[3:].decode("utf-8", "replace")) for r, b in enumerate(blobs) if not b.startswith(b"ok:")]
+        if bad:
+            raise CommUnavailable("%s failed on %d of %d ranks (%s)" % (key, len(bad), self.world, "; ".join(bad)))
+        return [b[3:] for b in blobs]
+
+    def cleanup(self):
+        """Remove this rank's own files (call only once every rank is known to have read them)."""
+        for path in self._mine:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        self._mine = []
+
+
+def comm_exchange_id(make_id, rank, world, timeout_s=180.0, rdv=None):
+    """Rank 0 calls make_id() -> bytes and publishes them; every rank returns the same bytes.  If rank 0 cannot
+    make one it says so through the same file and the others stop waiting at once."""
+    rdv = rdv or Rendezvous(rank, world, timeout_s)
     if rank == 0:
         try:
             blob = make_id()
         except Exception:
-            publish(b"FAILED")                   # the others stop waiting at once and take the same fallback
+            rdv.publish("id", b"FAILED")
             raise
-        publish(blob)
+        rdv.publish("id", blob)
         return blob
-    t0 = time.time()
-    while True:
-        try:
-            with open(path, "rb") as f:
-                blob = f.read()
-            if len(blob) == 128:
-                return blob
-            if blob == b"FAILED":
-                raise RuntimeError("rank 0 could not create an RCCL id")
-        except FileNotFoundError:
-            pass
-        if time.time() - t0 > timeout_s:
-            raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout_s))
-        time.sleep(0.02)
+    blob = rdv.collect("id", [0])[0]
+    if blob == b"FAILED":
+        raise RuntimeError("rank 0 could not create an RCCL id")
+    return blob
 
 
-def comm_init(ctx, rank, world):
-    """Collective: give `ctx` an RCCL communicator spanning the `world` ranks of this node."""
-    import ctypes
-    import os
+def collective_init(rdv, probe, make_id, init, destroy):
+    """The agreement around ncclCommInitRank, which cannot time out: (1) every rank loads RCCL (`probe`) and rank 0
+    makes the id; all ranks learn whether all could, and nobody enters the collective otherwise; (2) every rank runs
+    `init(id)`; all ranks learn whether all succeeded, and those that did `destroy()` their communicator
+    otherwise.  Either every rank returns, or every rank raises CommUnavailable."""
+    blob, err = b"", None
+    try:
+        probe()
+        if rdv.rank == 0:
+            blob = make_id()
+    except Exception as e:                        # noqa: BLE001 -- reported to every rank below
+        err = e
+    blobs = rdv.agree("probe", err is None, blob if err is None else repr(err).encode())
+    err = None
+    try:
+        init(blobs[0])
+    except Exception as e:                        # noqa: BLE001
+        err = e
+    try:
+        rdv.agree("init", err is None, b"" if err is None else repr(err).encode())
+    except CommUnavailable:
+        if err is None:
+            destroy()
+        raise
+
+
+def comm_init(ctx, rank, world, timeout_s=180.0):
+    """Collective: give `ctx` an RCCL communicator spanning the `world` ranks of this node.  Raises
+    CommUnavailable on every rank if any rank cannot (see collective_init)."""
     lib = ctx.lib
+
+    def probe():
+        _native._check(lib.gme_comm_probe(), lib)
 
     def make_id():
         buf = ctypes.create_string_buffer(128)
         _native._check(lib.gme_comm_unique_id(buf), lib)
         return buf.raw
-    blob = comm_exchange_id(make_id, rank, world) if world > 1 else make_id()
-    _native._check(lib.gme_comm_init(ctx.handle, blob, rank, world), lib)
-    comm_barrier(ctx)
-    if rank == 0 and world > 1:
-        try:
-            os.unlink(_id_file())
-        except OSError:
-            pass
+
+    def init(blob):
+        _native._check(lib.gme_comm_init(ctx.handle, blob, rank, world), lib)
+
+    if world == 1:
+        probe()
+        init(make_id())
+        comm_barrier(ctx)
+        return
+    rdv = Rendezvous(rank, world, timeout_s)
+    collective_init(rdv, probe, make_id, init, lambda: comm_destroy(ctx))
+    comm_barrier(ctx)                            # every rank has read every file once this returns
+    rdv.cleanup()
+
+
+def comm_info(ctx):
+    """(rank, world) as RCCL itself reports them for the context's communicator (ncclCommUserRank / ncclCommCount)."""
+    r, n = ctypes.c_int(-1), ctypes.c_int(-1)
+    _native._check(ctx.lib.gme_comm_info(ctx.handle, ctypes.byref(r), ctypes.byref(n)), ctx.lib)
+    return r.value, n.value
 
 
 def comm_destroy(ctx):
@@ -127,7 +238,6 @@ def comm_destroy(ctx):
 
 
 def comm_max(ctx, value):
-    import ctypes
     v = np.array([float(value)], dtype=np.float64)
     _native._check(ctx.lib.gme_comm_allreduce_max(ctx.handle, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1), ctx.lib)
     return float(v[0])
@@ -146,7 +256,6 @@ def pad_and_trim(n_pairs, world):
 
 def gather_parameters_rccl(ctx, local, n_pairs, rank, world):
     """gather_parameters over the library's RCCL communicator (gme_shard_gather)."""
-    import ctypes
     local = np.ascontiguousarray(local, dtype=np.float64)
     k = local.shape[1] if local.ndim == 2 else 6
     longest, sizes = pad_and_trim(n_pairs, world)
@@ -361,5 +470,14 @@ class ShardedSequence:
         lane, k = self._lane_of(pair)
         return lane.seq.read_compensated(k)
 
-    def gather(self, local_rows, device=None):
-        return gather_parameters(local_rows, self.n_pairs_total, self.rank, self.world, device)
+    def gather(self, local_rows):
+        """All-gather of this shard's per-pair rows (float64[P_local, k]) -> float64[P_total, k] on every rank, over the
+        context's RCCL communicator (comm_init first); the identity on a single rank."""
+        if self.world == 1:
+            return np.ascontiguousarray(local_rows, dtype=np.float64)
+        return gather_parameters_rccl(self.ctx, local_rows, self.n_pairs_total, self.rank, self.world)
+
+    def unpad(self, gathered):
+        """float64[world, n_max, k] blocks of a fixed-size all-gather -> float64[P_total, k]."""
+        _, sizes = pad_and_trim(self.n_pairs_total, self.world)
+        return np.concatenate([gathered[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)

@@ -188,7 +188,21 @@ GME_API int gme_seq_wait(gme_seq *seq);
  *   gme_shard_gather     rows[n_local][k] of every rank -> out[world][n_max][k], blocks zero-padded to
  *                        n_max rows (n_max = the largest shard, the same on every rank); synchronises
  *   gme_comm_allreduce_max   element-wise max of v[n] over the ranks, in place (barrier; max-over-ranks time)
+ *   gme_comm_probe       loads librccl.so and nothing else: a launcher lets every rank probe and agree BEFORE any rank
+ *                        enters the collective gme_comm_init (which cannot time out), sequence.comm_init does
+ *   gme_comm_info        rank and rank count as RCCL reports them (ncclCommUserRank / ncclCommCount)
+ *   gme_seq_mv_summary   per-pair summary rows of the last gme_seq_bbme field, float64[P][6] = modal vector x, y (over the
+ *                        vectors inside [-64, 64)^2, ties to the smaller (x+64)*128 + (y+64)), its block count, sum of
+ *                        x, sum of y, checksum sum_i ((i mod 251) + 1)(3 x_i + 5 y_i) over the blocks in row-major
+ *                        order -- what a sharded bbme.get_motion_field run (bbme.py:12-38 per pair, results.py:41-50 over
+ *                        pairs) exchanges instead of its 10.8 kB fields; synchronises
+ *   gme_seq_mv_summary_gather   the same rows all-gathered device to device: out[world][n_max][6], blocks zero-padded
+ *                        to n_max >= this rank's pairs (the same on every rank); split-phase aware (gme_seq_wait)
  * ------------------------------------------------------------------------- */
+GME_API int gme_comm_probe(void);
+GME_API int gme_comm_info(gme_ctx *ctx, int *rank_out, int *world_out);
+GME_API int gme_seq_mv_summary(gme_seq *seq, double *rows_out);
+GME_API int gme_seq_mv_summary_gather(gme_seq *seq, int n_max, double *out);
 GME_API int gme_comm_unique_id(char id_out[128]);
 GME_API int gme_comm_init(gme_ctx *ctx, const char id[128], int rank, int world);
 GME_API int gme_comm_destroy(gme_ctx *ctx);

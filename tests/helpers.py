@@ -148,3 +148,46 @@ def oracle_results_flow(prev, cur, bs=16, procedure=3, sw=2):
 def sha(a):
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gather_rows_torch(local, n_pairs, rank, world, device=None):
+    """The path's one exchange over torch.distributed (gloo in the CPU tests and rehearsals; nccl = RCCL as
+    bench.py's collectively agreed fallback transport): all-gather of per-pair rows -> float64[n_pairs, k] on every
+    rank, padded to the largest shard like gme_shard_gather.  Test / bench plumbing: the product path uses the
+    library's own communicator (sequence.gather_parameters_rccl)."""
+    import sequence
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if world == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+    k = local.shape[1] if local.ndim == 2 else 6
+    longest, sizes = sequence.pad_and_trim(n_pairs, world)
+    buf = torch.zeros((longest, k), dtype=torch.float64)
+    if len(local):
+        buf[:len(local)] = torch.from_numpy(local)
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return np.concatenate([o.cpu().numpy()[:b - a] for o, (a, b) in zip(out, sizes)], axis=0)
+
+
+def mv_summary_rows(mf):
+    """NumPy statement of gme_seq_mv_summary (include/gme_hip.h) for int32[P, h, w, 2] fields -> float64[P, 6]:
+    modal vector x, y over the vectors inside [-64, 64)^2 (ties: smaller (x+64)*128 + (y+64)), its count,
+    sum x, sum y, checksum sum_i ((i mod 251) + 1)(3 x_i + 5 y_i)."""
+    mf = np.asarray(mf, dtype=np.int64)
+    if mf.ndim == 3:
+        mf = mf[None]
+    out = np.zeros((mf.shape[0], 6))
+    for p, f in enumerate(mf):
+        x, y = f[..., 0].ravel(), f[..., 1].ravel()
+        inside = (x >= -64) & (x < 64) & (y >= -64) & (y < 64)
+        if inside.any():
+            counts = np.bincount(((x[inside] + 64) * 128 + (y[inside] + 64)).astype(np.int64), minlength=128 * 128)
+            b = int(np.argmax(counts))                       # first maximum = smallest bin
+            out[p, :3] = (b // 128 - 64, b % 128 - 64, counts[b])
+        wgt = np.arange(len(x), dtype=np.int64) % 251 + 1
+        out[p, 3:] = (x.sum(), y.sum(), int((wgt * (3 * x + 5 * y)).sum()))
+    return out

@@ -516,12 +516,40 @@ def test_rccl_self_gather_world_1(native):
     assert sequence.gather_parameters_rccl(ctx, np.zeros((0, 6)), 0, 0, 1).shape == (0, 6)
     assert sequence.comm_max(ctx, 2.5) == 2.5
     sequence.comm_barrier(ctx)
+    assert sequence.comm_info(ctx) == (0, 1)                # what ncclCommUserRank / ncclCommCount report
     # the communicator rides on the context's stream next to the kernels
     seq = native.Sequence(ctx, 3, 64, 96)
     seq.synth(1, 0)
     seq.bbme(1, 16, 8, 0, 0)
     assert np.array_equal(sequence.gather_parameters_rccl(ctx, rows[:3], 3, 0, 1), rows[:3])
     assert seq.read_mv().shape == (2, 4, 6, 2)
+    seq.close()
+    # the per-step exchange of a sharded block-matching run: summary rows all-gathered device to device
+    # (gme_seq_mv_summary_gather), blocking and split-phase with two result slots, padded to n_max rows
+    from helpers import mv_summary_rows
+    seq = native.Sequence(ctx, 9, 96, 160)
+    seq.synth(1234, 3)
+    for proc, sw in ((0, 16), (3, 2), (2, 16)):
+        seq.bbme(1, 16, sw, proc, 1)
+        want = mv_summary_rows(seq.read_mv())
+        assert np.array_equal(seq.mv_summary(), want), proc
+        got = seq.mv_summary_gather(11, 1)
+        assert got.shape == (1, 11, 6) and np.array_equal(got[0, :8], want) and not got[0, 8:].any(), proc
+    shard = sequence.ShardedSequence(96, 160, 9, 1, ctx=ctx)
+    assert np.array_equal(shard.unpad(got[:, :8]), want) and np.array_equal(shard.gather(want), want)
+    seq.set_split_phase(True)
+    seq.bbme(1, 16, 16, 0, 0)
+    a = seq.mv_summary_gather(8, 1, slot=0)
+    seq.wait()
+    first = np.array(a)
+    seq.synth(1234, 40)
+    seq.bbme(1, 16, 16, 0, 0)
+    b = seq.mv_summary_gather(8, 1, slot=1)                # queued while `a` is still being read
+    seq.wait()
+    assert np.array_equal(a, first) and np.array_equal(b[0], mv_summary_rows(seq.read_mv())) and not np.array_equal(a, b)
+    seq.set_split_phase(False)
+    with pytest.raises(IndexError):
+        seq.mv_summary_gather(3, 1)                         # fewer rows than this rank has pairs
     seq.close()
     with pytest.raises(native.GmeError):
         sequence.comm_init(ctx, 0, 1)                       # one communicator per context
@@ -551,6 +579,14 @@ def test_streamed_upload_equals_resident(native, pinned):
             assert np.array_equal(got[p], co.bbme(src[p], src[p + fd], 16, sw, proc, pn)), (fd, sw, proc, pn, chunk, p)
         seq.bbme(fd, 16, sw, proc, pn)                      # the frames stay resident
         assert np.array_equal(seq.read_mv(), got)
+    # the streamed call keeps its per-frame table of box sums of squares for later calls; a later exhaustive
+    # MSE search with a SMALLER frame distance reads the rows of frames [fd_small, fd_streamed) as `cur` too
+    for chunk in (64, 5, 2):
+        seq.bbme_streamed(frames, 3, 16, 16, 0, 1, chunk_frames=chunk)
+        seq.bbme(1, 16, 16, 0, 1)
+        got = seq.read_mv()
+        for p in (0, 1, 2, 3, n - 2):
+            assert np.array_equal(got[p], co.bbme(src[p], src[p + 1], 16, 16, 0, 1)), (chunk, p)
     part = seq.bbme_streamed(frames[:9], 1, 16, 16, 0, 0, chunk_frames=4)      # fewer frames than the sequence holds
     assert part.shape[0] == 8 and np.array_equal(part[7], co.bbme(src[7], src[8], 16, 16, 0, 0))
     with pytest.raises(IndexError):

@@ -125,18 +125,33 @@ def test_shard_ranges_cover_pairs_once():
 
 _GATHER = r'''
 import os, sys
-sys.path[:0] = [%(pkg)r]
+sys.path[:0] = [%(pkg)r, %(tests)r]
 import numpy as np, torch.distributed as dist
 import sequence
+from helpers import gather_rows_torch, mv_summary_rows
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 n = 7
 a, b = sequence.shard_range(n, rank, world)
 local = np.arange(n * 6, dtype=np.float64).reshape(n, 6)[a:b] * 1.5
-full = sequence.gather_parameters(local, n, rank, world)
+full = gather_rows_torch(local, n, rank, world)
 assert full.shape == (n, 6) and np.array_equal(full, np.arange(n * 6, dtype=np.float64).reshape(n, 6) * 1.5)
-empty = sequence.gather_parameters(np.zeros((1 if rank == 0 else 0, 6)), 1, rank, world)
+empty = gather_rows_torch(np.zeros((1 if rank == 0 else 0, 6)), 1, rank, world)
 assert empty.shape == (1, 6)
+# the row exchange of a sharded block-matching run (bench.py at N > 1): every rank summarises the fields of ITS
+# pairs into 48-byte rows, the all-gather hands every rank all of them, in pair order
+rng = np.random.default_rng(5)
+fields = rng.integers(-16, 32, (n, 30, 45, 2)).astype(np.int32)             # the same on every rank (same seed)
+rows = gather_rows_torch(mv_summary_rows(fields[a:b]), n, rank, world)
+assert rows.shape == (n, 6) and np.array_equal(rows, mv_summary_rows(fields))
+# the fixed-size blocks gme_seq_mv_summary_gather returns ([world][n_max][6], zero-padded) unpad to the same rows
+shard = sequence.ShardedSequence.__new__(sequence.ShardedSequence)
+shard.n_pairs_total, shard.world = n, world
+longest, sizes = sequence.pad_and_trim(n, world)
+blocks = np.zeros((world, longest, 6))
+for r, (lo, hi) in enumerate(sizes):
+    blocks[r, :hi - lo] = rows[lo:hi]
+assert np.array_equal(shard.unpad(blocks), rows)
 dist.barrier()
 dist.destroy_process_group()
 sys.stdout.write("rank" + str(rank) + " ok\n")
@@ -145,7 +160,7 @@ sys.stdout.write("rank" + str(rank) + " ok\n")
 
 def test_gather_over_gloo_world_2(tmp_path):
     script = tmp_path / "gather.py"
-    script.write_text(_GATHER % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
+    script.write_text(_GATHER % {"pkg": os.path.join(REPO, "global-motion-estimation_amd"), "tests": os.path.join(REPO, "tests")})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
@@ -235,8 +250,9 @@ def test_rccl_id_rendezvous_and_padding(tmp_path):
     for r, p in zip((1, 2), late):
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0 and ("rank%d got the id" % r) in out
-    path = "/tmp/gme_rccl_29777_%d.id" % os.getpid()
-    assert os.path.exists(path)
+    path = "/tmp/gme_rccl_%d/29777_%d.id.0" % (os.getuid(), os.getpid())       # a private directory, keyed by port and parent
+    assert os.path.exists(path) and (os.stat(path).st_mode & 0o777) == 0o600
+    assert (os.stat(os.path.dirname(path)).st_mode & 0o777) == 0o700
     os.unlink(path)
     # rank 0 cannot make an id: it says so through the same file and the others give up at once (no 3-minute wait)
     os.environ["GME_COMM_ID_FILE"] = str(tmp_path / "failed.id")
@@ -263,6 +279,66 @@ def test_rccl_id_rendezvous_and_padding(tmp_path):
     assert np.array_equal(np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)]), full)
 
 
+_AGREE = r"""
+import os, sys
+sys.path[:0] = [%(pkg)r]
+import sequence
+rank, world, scenario = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+state = {"comm": False, "entered_init": False}
+def probe():
+    if scenario == "probe_fails_on_2" and rank == 2:
+        raise OSError("cannot open librccl.so")
+def make_id():
+    return bytes(range(128))
+def init(blob):
+    assert blob == bytes(range(128))
+    state["entered_init"] = True
+    if scenario == "init_fails_on_1" and rank == 1:
+        raise RuntimeError("ncclCommInitRank failed")
+    state["comm"] = True
+def destroy():
+    state["comm"] = False
+rdv = sequence.Rendezvous(rank, world, timeout_s=60)
+try:
+    sequence.collective_init(rdv, probe, make_id, init, destroy)
+    out = "up"
+except sequence.CommUnavailable as e:
+    out = "unavailable[%%s]" %% e
+sys.stdout.write("rank%%d %%s comm=%%s entered_init=%%s\n" %% (rank, out, state["comm"], state["entered_init"]))
+"""
+
+
+@pytest.mark.parametrize("scenario", ["all_fine", "probe_fails_on_2", "init_fails_on_1"])
+def test_comm_init_is_decided_by_all_ranks(tmp_path, scenario):
+    """VERDICT r2 / ADVICE: the transport is never chosen per rank.  sequence.collective_init wraps ncclCommInitRank in
+    two agreements over the file rendezvous: if any rank cannot load RCCL nobody enters the collective; if any rank's
+    init fails, the others give their communicator back; either way EVERY rank raises CommUnavailable (and bench.py then
+    takes the same fallback on every rank) or every rank is up.  A stale file of an earlier launch is never read."""
+    script = tmp_path / "agree.py"
+    script.write_text(_AGREE % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
+    base = str(tmp_path / "launch")
+    stale = base + ".probe.0"                              # an earlier launch with the same key died after saying "no"
+    with open(stale, "wb") as f:
+        f.write(b"no:stale failure marker")
+    os.utime(stale, (1.0e9, 1.0e9))
+    env = dict(os.environ, GME_COMM_ID_FILE=base)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", scenario], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in (2, 1, 0)]
+    outs = {}
+    for r, p in zip((2, 1, 0), procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err
+        outs[r] = out.strip()
+    if scenario == "all_fine":
+        assert all(outs[r] == "rank%d up comm=True entered_init=True" % r for r in range(3)), outs
+    elif scenario == "probe_fails_on_2":
+        assert all("unavailable[probe failed on 1 of 3 ranks (rank 2: OSError" in outs[r] for r in range(3)), outs
+        assert all("entered_init=False" in outs[r] for r in range(3)), outs      # nobody went into the collective
+    else:
+        assert all("unavailable[init failed on 1 of 3 ranks (rank 1: RuntimeError" in outs[r] for r in range(3)), outs
+        assert all("comm=False" in outs[r] for r in range(3)), outs              # ranks 0 and 2 gave theirs back
+
+
 def test_bench_helpers():
     """bench.py's sampling (first and last pair always in), content stacks and profile identity."""
     sys.path.insert(0, REPO)
@@ -275,6 +351,16 @@ def test_bench_helpers():
     f, h, w = bench.host_content("race", 5, 480, 720)
     assert f.shape == (5, 480, 720) and np.array_equal(f[0], f[2]) and not np.array_equal(f[0], f[1])
     assert bench.host_content("flat", 2, 32, 48)[0].min() == 128
+    f, h, w = bench.host_content("pan240x2", 60, 480, 720)          # 51 distinct real frames at 640x480
+    assert f.shape == (60, 480, 640) and (h, w) == (480, 640) and len({hash(x.tobytes()) for x in f[:51]}) == 51
+    small = bench.host_content("pan240seq", 3, 480, 720)[0]
+    assert np.array_equal(f[:3, 0::2, 0::2], small) and int(f[0, 1, 1]) == (int(small[0, :2, :2].astype(int).sum()) + 2) >> 2
+    # the PMC summary of a config is read for the kernel the launch plan names, not for whatever comes first in the file
+    vals, psha, name = bench.committed_profile("exh720", "k_exh_sea16p<3,5>")
+    assert name and name.endswith("_exh720_pmc_summary.txt") and vals["_kernel"].startswith("k_exh_sea16p<") and vals["FETCH_SIZE"] > 0
+    assert bench.committed_profile("exh720", "k_no_such_kernel<1>")[0] == {}
+    host = bench.host_description()
+    assert host["nproc"] >= 1 and host["numpy"] == np.__version__ and host["python"].count(".") == 2
     assert len(bench.kernel_source_sha()) == 16
     assert bench.byte_ops_per_pair(480, 720, 16, 16) == 2891044 * 256
 
