@@ -4,8 +4,10 @@
 // Bound.  For each 8x8 quadrant q, (sum(A_q) - sum(B_q))^2 <= 64 * SSD_q (Cauchy-Schwarz on the 64
 // pixel differences), hence  LBx = sum_q dS_q^2 <= 64 * SSD.  With a real candidate's SSD as UB,
 // a candidate with LBx > 64 * UB has SSD > UB >= min and can neither win nor tie.  Bounds travel
-// as 16-bit values floor(LBx / 2^14) against floor(64 * UB / 2^14) = UB >> 8; comparing floors only
-// ever keeps more candidates, never fewer.
+// as floor(LBx / 32) (25 bits: LBx < 2^30) against floor(64 * UB / 32) = 2 UB -- half an SSD unit of slack; comparing
+// floors only ever keeps more candidates, never fewer.  (Round 2 compared floor(LBx / 2^14) with UB >> 8: at the
+// UB of a good match, a few hundred, that let bounds up to 1.5 x the exact limit through.)  List entries keep 19 bits,
+// floor(LBx / 2^11), for the re-check against a tightened UB (UB >> 5).
 //
 // Same phases as k_exh_sea16 (bbme_sea.hip); what differs:
 //   B  dS_q by v_pk_sub_i16 on the packed quadrant sums, squares summed by v_dot2_i32_i16;
@@ -24,7 +26,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned long long u64min_(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
 
-// B: as lower_bounds() of bbme_sea.hip, with the squared bound floor(sum_q dS_q^2 / 2^14).
+// B: as lower_bounds() of bbme_sea.hip, with the squared bound: key = floor(sum_q dS_q^2 / 32) << 7 | local index.
 template <int R, bool GUARD>
 __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, int prow, int q, uint32_t a01, uint32_t a23,
                                                  int lo_r, int hi_r, int lo_c, int hi_c, uint32_t (&pkey)[R])
@@ -53,7 +55,7 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
                     const s16x2 dt = __builtin_bit_cast(s16x2, tp) - __builtin_bit_cast(s16x2, a01);   // |d| <= 16320
                     const s16x2 db = __builtin_bit_cast(s16x2, bt) - __builtin_bit_cast(s16x2, a23);
                     const uint32_t lbx = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
-                    pkey[k] = min(pkey[k], ((lbx >> 14) << 13) + (uint32_t)((4 * k + e) * R + i));
+                    pkey[k] = min(pkey[k], ((lbx >> 5) << 7) + (uint32_t)((4 * k + e) * R + i));      // local < 4R*R <= 100 < 128
                 }
             }
         }
@@ -102,15 +104,15 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         uint32_t patch_lb[R], lb_key = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 13;
+            patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 7;      // floor(LBx / 32), 25 bits
             lb_key = min(lb_key, pkey[k]);
         }
-        if (lb_key != 0xFFFFFFFFu) lb_key += (uint32_t)lane << 7;
         // ---- C
-        lb_key = wave_min_u32(lb_key);
+        const uint32_t lb_min = wave_min_u32(lb_key);      // the zero vector is always valid: never the sentinel
         unsigned long long ub_key = ~0ull;
         {
-            const int bl = (lb_key >> 7) & 63, loc = lb_key & 127;
+            // the key has no room for the lane number: the first lane that holds the minimum names the candidate
+            const int bl = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(lb_key == lb_min)) - 1), loc = lb_min & 127;
             const int ce = loc / R, li = loc - ce * R;
             const int idx1 = ((bl & 3) * 4 * R + ce) * NC + (bl >> 2) * R + li;
             const int idx0 = d.sw * NC + d.sw;
@@ -129,7 +131,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         }
         if (lane == 0) best[wave] = ub_key;
         // ---- D
-        const uint32_t ub16 = (uint32_t)(ub_key >> 21);                // (ssd >> 8) = floor(64 * ssd / 2^14)
+        const uint32_t ub25 = (uint32_t)(ub_key >> 12);                // 2 ssd = floor(64 * ssd / 32); ssd < 2^24
         // UB == 0 (an exact match is known): only another exact match earlier in scan order can replace it
         // (bbme.py:171 keeps the first minimum), so a patch needs a zero bound AND a first candidate in front
         // of the best one.  Flat or static content then leaves (almost) nothing instead of everything.
@@ -137,9 +139,9 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         const uint32_t ub_idx = (uint32_t)ub_key & 0x1FFFu, first_idx = (uint32_t)((q * 4 * R) * NC + prow * R);
 #pragma unroll
         for (int k = 0; k < R; ++k)
-            if (patch_lb[k] <= ub16 && (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
+            if (patch_lb[k] <= ub25 && (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
                 const uint32_t slot = atomicAdd(count, 1u);
-                work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | patch_lb[k];
+                work[slot] = ((uint32_t)wave << 28) | ((uint32_t)lane << 22) | ((uint32_t)k << 19) | (patch_lb[k] >> 6);   // NB <= 16 waves
             }
     }
     __syncthreads();
@@ -161,9 +163,9 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         uint32_t ent = 0;
         if (active) {
             ent = work[e];
-            active = (ent & 0xFFFFu) <= (uint32_t)(best[ent >> 25] >> 21);
+            active = (ent & 0x7FFFFu) <= (uint32_t)(best[ent >> 28] >> 18);          // floor(LBx / 2^11) vs ssd >> 5
         }
-        const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+        const int w2 = ent >> 28, l2 = (ent >> 22) & 63, k2 = (ent >> 19) & 7;
         const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;         // the patch's block inside the tile
         const int prow2 = l2 >> 2, q2 = l2 & 3;
         uint32_t acc[R][4];
