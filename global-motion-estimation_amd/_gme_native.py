@@ -359,7 +359,10 @@ class Sequence:
 
     def bbme_streamed(self, frames, frame_distance, block_size, search_window, procedure, pnorm, chunk_frames=128):
         """bbme() for frames that still live in host memory (uint8[n, H, W], n <= N): chunked upload on a
-        copy stream overlapped with the search of the previous chunk -> int32[n - fd, h, w, 2]."""
+        copy stream overlapped with the search of the previous chunk -> int32[n - fd, h, w, 2].
+
+        The array returned is a page-locked buffer that belongs to the sequence and is OVERWRITTEN by the next
+        bbme_streamed() call on it: copy it if it has to outlive that call ("Host frames, streamed")."""
         block_size = _block_size(block_size)
         frames = np.asarray(frames)
         if frames.ndim != 3 or frames.dtype != np.uint8 or frames.shape[1:] != (self.H, self.W):
@@ -412,6 +415,9 @@ class Sequence:
     # -- split-phase calls (gme_seq_set_split_phase): gme_begin / gme_fit / compensate queue their work and hand back
     #    page-locked arrays that are filled once wait() returns; one host thread can then drive several sequences
     def set_split_phase(self, on=True):
+        """Split-phase mode: upload / gme_begin / gme_fit / compensate / mv_summary_gather return once queued.  The arrays
+        they hand back are page-locked buffers owned by the sequence, one per call kind, REUSED by the next call of that
+        kind and valid only after wait(); the blocking helpers (motion.estimate_sequence) refuse a sequence in this mode."""
         _check(self.lib.gme_seq_set_split_phase(self.handle, int(bool(on))), self.lib)
         self._split = bool(on)                   # the page-locked buffers stay with the sequence for the next time
 

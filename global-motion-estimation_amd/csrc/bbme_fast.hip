@@ -41,15 +41,20 @@ struct FastDev {
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
 typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+// The anchor block is wave-uniform and the frames are never written by a search kernel: read through the constant
+// address space its 64 dwords become scalar loads (SGPRs) that no store or atomic of the kernel can alias -- also inside
+// the redo kernel's work loop, where plain global loads ended up in 86-128 VGPRs.
+typedef __attribute__((address_space(4))) const uint32_t const_u32;
+__device__ __forceinline__ const_u32* as_constant(const void* p) { return (const_u32*)(uintptr_t)p; }
 
 // ---- stage the search window (coalesced dword loads; out-of-frame -> 0) ----
 // thread -> one dword column and every `rstep`-th row: no div/mod inside the loop
-__device__ __forceinline__ void stage_window(const FastDev& d, uint32_t* win, const uint8_t* cur, int bcol0, int r0)
+__device__ __forceinline__ void stage_window(const FastDev& d, uint32_t* win, const uint8_t* cur, int bcol0, int r0, int tid)
 {
     const int gx0 = bcol0 * 16 - d.sw;             // multiple of 4 (sw % 4 == 0)
     const int gy0 = r0 - d.sw;
     const int rstep = blockDim.x / d.pitch_dw;
-    const int row0 = threadIdx.x / d.pitch_dw, dw = threadIdx.x - row0 * d.pitch_dw;
+    const int row0 = tid / d.pitch_dw, dw = tid - row0 * d.pitch_dw;
     const int gx = gx0 + 4 * dw;
     const bool colok = gx >= 0 && gx < d.pitch;
     if (row0 < rstep) {
@@ -71,22 +76,21 @@ __device__ __forceinline__ void stage_window(const FastDev& d, uint32_t* win, co
 // row is read just before its first use (one broadcast ds_read_b128, R rows live) instead of sitting in 64
 // SGPRs -- the form the redo loop uses, where the compiler cannot keep the scalar loads (see k_exh_redo16).
 template <int R, bool ALDS = false>
-__device__ __forceinline__ void qsad16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0,
+__device__ __forceinline__ void qsad16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0, int tid,
                                              const uint32_t* alds = nullptr)
 {
     constexpr int NW = R + 3;                          // 64-bit window pairs per lane and row
     const int r0 = brow * 16;
     const int NC = 2 * d.sw + 16;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bcol = bcol0 + wave;
     if (bcol >= d.nbc) return;                         // ragged last workgroup
     const int c0 = bcol * 16;
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     const int prow = lane >> 2, q = lane & 3;
 
     // ---- anchor block: 64 wave-uniform dwords (scalar loads -> SGPRs) ----
-    const uint32_t* anchor = (const uint32_t*)(d.prev + (long long)pair * d.plane_stride +
-                                               (long long)r0 * d.pitch + c0);
+    const_u32* anchor = as_constant(d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0);
     const int apitch = d.pitch >> 2;
     uint32_t A[16][4];
     if (!ALDS) {
@@ -191,9 +195,9 @@ __global__ void __launch_bounds__(384) k_exh_qsad16(FastDev d)
     const int wg = (b >> 3) % d.wg_per_pair;
     const int brow = wg / d.wg_per_row;
     const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
-    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16, (int)threadIdx.x);
     __syncthreads();
-    qsad16_block<R>(d, win, pair, brow, bcol0);
+    qsad16_block<R>(d, win, pair, brow, bcol0, (int)threadIdx.x);
 }
 
 // Redo form (hostile tiles of the elimination kernels, bbme_sea_common.h: SeaDev::redo_list): a fixed grid
@@ -216,21 +220,21 @@ struct RedoDev {
 // All terms are exact integers < 2^26 (bs = 16), equal to the reference's float32 sums (bbme.py:94).
 // ---------------------------------------------------------------------------
 template <int R, bool ALDS = false>
-__device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0,
+__device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0, int tid,
                                             const uint32_t* alds = nullptr)
 {
     constexpr int NW = R + 4;                          // window dwords per lane and row
     const int r0 = brow * 16;
     const int NC = 2 * d.sw + 16;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bcol = bcol0 + wave;
     if (bcol >= d.nbc) return;
     const int c0 = bcol * 16;
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     const int prow = lane >> 2, q = lane & 3;
 
     const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
-    const uint32_t* anchor = (const uint32_t*)aptr;
+    const_u32* anchor = as_constant(aptr);
     const int apitch = d.pitch >> 2;
     uint32_t A[16][4];
     if (!ALDS) {
@@ -301,22 +305,40 @@ __device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* wi
     // ---- costs and the first minimum in scan order (column index outer, row index inner) ----
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
     const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
-    const uint32_t* sq = d.sqbox + (long long)pair * d.sqbox_stride;
+    const SqTable sq = sq_table(d.sqbox + (long long)pair * d.sqbox_stride, d.H, d.pitch);
     uint32_t bcost = 0xFFFFFFFFu;
     int blocal = 0;
+    const bool interior = __builtin_amdgcn_readfirstlane(lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1);
+    if (interior) {
+        // whole window inside the frame: the four candidates 4k .. 4k+3 of a row share one 8-byte + one 4-byte table read
 #pragma unroll
-    for (int k = 0; k < R; ++k)
+        for (int k = 0; k < R; ++k) {
+            uint32_t b2[R][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int i = 0; i < R; ++i) sq4(sq, (long long)(r0 - d.sw + prow * R + i) * d.pitch + (c0 - d.sw + q * 4 * R + 4 * k), b2[i]);
 #pragma unroll
-            for (int i = 0; i < R; ++i) {              // local scan order: (4k+e) outer, i inner
-                const int ri = prow * R + i, ci = q * 4 * R + 4 * k + e;
-                if (ri >= lo_r && ri <= hi_r && ci >= lo_c && ci <= hi_c) {
-                    const uint32_t b2 = sq[(long long)(r0 - d.sw + ri) * d.pitch + (c0 - d.sw + ci)];
-                    const uint32_t cost = a2 + b2 - 2u * acc[i][k][e];
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
+                    const uint32_t cost = a2 + b2[i][e] - 2u * acc[i][k][e];
                     if (cost < bcost) { bcost = cost; blocal = (4 * k + e) * R + i; }
                 }
-            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
+                    const int ri = prow * R + i, ci = q * 4 * R + 4 * k + e;
+                    if (ri >= lo_r && ri <= hi_r && ci >= lo_c && ci <= hi_c) {
+                        const uint32_t b2 = sq1(sq, (long long)(r0 - d.sw + ri) * d.pitch + (c0 - d.sw + ci));
+                        const uint32_t cost = a2 + b2 - 2u * acc[i][k][e];
+                        if (cost < bcost) { bcost = cost; blocal = (4 * k + e) * R + i; }
+                    }
+                }
+    }
     unsigned long long best = ~0ull;
     if (bcost != 0xFFFFFFFFu) {
         const int ce = blocal / R, i = blocal - ce * R;
@@ -348,56 +370,48 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
     const int wg = (b >> 3) % d.wg_per_pair;
     const int brow = wg / d.wg_per_row;
     const int bcol0 = (wg - brow * d.wg_per_row) * d.nb;
-    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
+    stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16, (int)threadIdx.x);
     __syncthreads();
-    dot16_block<R>(d, win, pair, brow, bcol0);
+    dot16_block<R>(d, win, pair, brow, bcol0, (int)threadIdx.x);
 }
 
-// In this loop form the compiler no longer keeps the 64 anchor dwords in SGPRs (the field stores and counter
-// atomics of earlier rounds may alias the frames as far as it can prove, and SGPRs are short anyway): it moved
-// them to VGPRs (86-128 per wave, scratch for MSE).  So the anchors are staged in LDS here and read row by row
-// (ALDS form of the search bodies): 60-80 VGPRs, no scratch.
+// The work-loop form of the two bodies above.  The anchors stay scalar here too (constant address space, see
+// as_constant): with plain global loads the compiler moved them to VGPRs inside the loop (86-128 per wave), round 2
+// staged them in LDS instead (82 / 117 VGPRs: 5 / 4 waves per SIMD).
 template <int R, bool MSE>
-__global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d0, RedoDev r, const uint8_t* __restrict__ prev,
-                                                        const uint8_t* __restrict__ cur, int32_t* __restrict__ mf,
-                                                        const uint32_t* __restrict__ list, uint32_t* __restrict__ head)
+__global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
 {
     extern __shared__ uint32_t win[];
     __shared__ uint32_t item_s;
-    FastDev d = d0;
-    d.prev = prev; d.cur = cur; d.mf = mf;
     const uint32_t total = *r.count * (uint32_t)r.tr;
     if (total == 0) return;                                // friendly content: nothing was listed, no atomic is spent
     for (;;) {
-        if (threadIdx.x == 0) item_s = atomicAdd(head, 1u);
+        if (threadIdx.x == 0) item_s = atomicAdd(r.head, 1u);
         __syncthreads();
         const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_s);
         if (item >= total) break;
-        const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[item / (uint32_t)r.tr]);
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.list[item / (uint32_t)r.tr]);
         const int row_in_tile = (int)(item % (uint32_t)r.tr), xcd = (int)(ent & 7u), t = (int)(ent >> 3);
         const int lp = t / r.tile_wg_per_pair, wg = t - lp * r.tile_wg_per_pair;
         const int trow = wg / r.tile_wg_per_row, bcol0 = (wg - trow * r.tile_wg_per_row) * d.nb;
         const int pair = lp * 8 + xcd, brow = trow * r.tr + row_in_tile;
         const bool ok = brow < d.nbr && pair < d.pairs;                                     // ragged last tile row
-        uint32_t* alds = win + d.win_rows * d.pitch_dw;                                      // [nb][64] anchors
-        if (ok) {
-            stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16);
-            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-            if (bcol0 + wave < d.nbc)
-                alds[wave * 64 + lane] = *(const uint32_t*)(d.prev + (long long)pair * d.plane_stride +
-                                                            (long long)(brow * 16 + (lane >> 2)) * d.pitch + (bcol0 + wave) * 16 + (lane & 3) * 4);
-        }
+        // everything derived from the thread index is recomputed per item from an opaque copy: hoisted out of the work loop
+        // those values (window offsets, table addresses) cost ~45 VGPRs in the MSE body (112 against the 66 of k_exh_dot16)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (ok) stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16, tid);
         __syncthreads();
         if (ok) {
-            if (MSE) dot16_block<R, true>(d, win, pair, brow, bcol0, alds);
-            else qsad16_block<R, true>(d, win, pair, brow, bcol0, alds);
+            if (MSE) dot16_block<R>(d, win, pair, brow, bcol0, tid);
+            else qsad16_block<R>(d, win, pair, brow, bcol0, tid);
         }
         __syncthreads();                                   // the next item restages `win` and redraws item_s
     }
 }
 
-// 16x16 box sums of squares of one plane stack in ONE pass (5.5 bytes of HBM traffic per pixel
-// instead of the ~15 of a rows pass + a columns pass through a uint32 scratch plane).
+// 16x16 box sums of squares of one plane stack in ONE pass (4 bytes of HBM traffic per pixel: 1 read, 3 written;
+// round 2 wrote uint32 sums, 5 bytes per pixel, and this kernel was 15 % of the exhaustive MSE step).
 // Thread -> four adjacent columns x .. x+3 (x % 4 == 0) of a chunk of SQ_CHUNK output rows:
 //   h(row) = the four horizontal 16-byte sums of squares of `row`: five aligned dwords, three
 //            v_alignbyte copies of each, sixteen v_dot4(b, b);
@@ -434,7 +448,9 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SQ_CHUNK;
     if (x > W - 16 || y0 > H - 16) return;
     const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y0 * pitch + x;
-    uint32_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y0 * pitch + x;
+    const SqTable tab = sq_table(dst + (long long)blockIdx.z * dst_stride, H, pitch);
+    uint16_t* olo = (uint16_t*)tab.lo + (long long)y0 * pitch + x;
+    uint8_t* ohi = (uint8_t*)tab.hi + (long long)y0 * pitch + x;
     u32x4_v ring[16], s = { 0, 0, 0, 0 };
 #pragma unroll
     for (int r = 0; r < 15; ++r) {                       // rows y0 .. y0+14 <= H-2
@@ -449,7 +465,11 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
             if (k <= last) {
                 const u32x4_v h = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);   // row y0+k+15 <= H-1
                 s += h;
-                *(u32x4_v*)(o + (long long)k * pitch) = s;
+                // 24-bit sums (16 * 16 * 255^2 < 2^24) as a 16-bit and an 8-bit plane: 3 bytes per position, aligned 8- and 4-byte stores
+                const uint32_t l01 = __builtin_amdgcn_perm(s.y, s.x, 0x05040100u), l23 = __builtin_amdgcn_perm(s.w, s.z, 0x05040100u);
+                const uint32_t h8 = __builtin_amdgcn_perm(s.y, s.x, 0x0C0C0602u) | (__builtin_amdgcn_perm(s.w, s.z, 0x0C0C0602u) << 16);
+                *(uint2*)(olo + (long long)k * pitch) = make_uint2(l01, l23);
+                *(uint32_t*)(ohi + (long long)k * pitch) = h8;
                 s -= ring[u];                            // h(y0 + k): row r lives in ring[r & 15]
                 ring[(u + 15) & 15] = h;
             }
@@ -553,7 +573,7 @@ int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int
     d.win_rows = 16 * R + 15;
     const int need_dw = (tc - 1) * 4 + 3 * R + (R + 2) + 2;
     d.pitch_dw = pick_pitch_dw(need_dw, R);
-    const size_t lds = (size_t)d.win_rows * d.pitch_dw * 4 + (size_t)tc * 256;       // window + one anchor per wave
+    const size_t lds = (size_t)d.win_rows * d.pitch_dw * 4;
     RedoDev r;
     r.list = list; r.count = count; r.head = head;
     r.tr = tr; r.tile_wg_per_row = tile_wg_per_row; r.tile_wg_per_pair = tile_wg_per_pair;
@@ -567,8 +587,8 @@ int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int
     const long long max_items = (long long)job.pairs * tile_wg_per_pair * tr;
     if (groups > max_items) groups = max_items;
     const dim3 grid((unsigned)groups), block(64 * tc);
-#define REDO_LAUNCH(RR) do { if (mse) hipLaunchKernelGGL((k_exh_redo16<RR, true>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); \
-                             else hipLaunchKernelGGL((k_exh_redo16<RR, false>), grid, block, lds, ctx->stream, d, r, d.prev, d.cur, d.mf, list, head); } while (0)
+#define REDO_LAUNCH(RR) do { if (mse) hipLaunchKernelGGL((k_exh_redo16<RR, true>), grid, block, lds, ctx->stream, d, r); \
+                             else hipLaunchKernelGGL((k_exh_redo16<RR, false>), grid, block, lds, ctx->stream, d, r); } while (0)
     switch (R) {
     case 1: REDO_LAUNCH(1); break;
     case 2: REDO_LAUNCH(2); break;

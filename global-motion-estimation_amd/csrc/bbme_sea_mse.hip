@@ -155,7 +155,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
     // repeat some v_alignbyte work but put four times as many waves on the (long) evaluation.
     constexpr int LPP = LPPT, AR = 16 / LPP;
     const int n = (int)*count;
-    const uint32_t* tab = d.sqbox + (long long)pair * d.sqbox_stride;
+    const SqTable tab = sq_table(d.sqbox + (long long)pair * d.sqbox_stride, d.H, d.pitch);
     for (int base = 0; base < n; base += T / LPP) {
         const int e = base + tid / LPP;
         const int sub = lane & (LPP - 1);
@@ -231,13 +231,11 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
             const uint32_t a2 = a2s[w2];
             unsigned long long key = ~0ull;
             const int ci0 = q2 * 4 * R + 4 * k2, ri0 = prow2 * R;
-            const uint32_t* tabrow = tab + (long long)(r02 - d.sw + ri0) * d.pitch + (c02 - d.sw + ci0);
+            const long long tabrow = (long long)(r02 - d.sw + ri0) * d.pitch + (c02 - d.sw + ci0);     // % 4 == 0
             if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
                 uint32_t b2[R][4];                             // all table reads in flight before the first use
 #pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) b2[i][e4] = tabrow[(long long)i * d.pitch + e4];
+                for (int i = 0; i < R; ++i) sq4(tab, tabrow + (long long)i * d.pitch, b2[i]);
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4)
 #pragma unroll
@@ -254,7 +252,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
                     for (int i = 0; i < R; ++i) {
                         const int ri = ri0 + i;
                         if (ri < lo_r2 || ri > hi_r2) continue;
-                        const uint32_t cost = a2 + tabrow[(long long)i * d.pitch + e4] - 2u * acc[i][e4];
+                        const uint32_t cost = a2 + sq1(tab, tabrow + (long long)i * d.pitch + e4) - 2u * acc[i][e4];
                         key = u64min_(key, ((unsigned long long)cost << 13) | (unsigned)(ci * NC + ri));
                     }
                 }

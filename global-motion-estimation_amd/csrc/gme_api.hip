@@ -430,6 +430,8 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     if (s->summary) hipFree(s->summary);
     if (s->gathered) hipFree(s->gathered);
     if (s->ready) hipEventDestroy(s->ready);
+    if (s->upload_gate) hipEventDestroy(s->upload_gate);
+    if (s->uploaded) hipEventDestroy(s->uploaded);
     delete s;
 }
 
@@ -464,13 +466,24 @@ static void gme_drop_run(gme_seq* s)
     s->gme_pairs = 0;
 }
 
-extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* frames, int row_stride,
-                              int64_t frame_stride)
+// One upload lane per device for the split-phase uploads of ALL contexts: host-to-device copies issued from several
+// streams at once share the link badly (two concurrent copy streams moved 22-25 GB/s where one moves 38-54, DESIGN.md
+// section 5; three lanes uploading on their own streams reached 62 % of the copy-alone rate, one shared lane does the
+// rest), so they queue on ONE stream in call order; events tie each copy to its sequence's own stream.
+namespace {
+struct Uploader {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    uint8_t* stage = nullptr;        // device staging of tight host frames, repacked into the pitched planes
+    size_t stage_bytes = 0;
+};
+Uploader g_uploader[16];
+}  // namespace
+
+// the copies of one gme_seq_upload call on `stream`; `stage` / `stage_bytes` is the staging buffer that belongs to that stream
+static int upload_copies(gme_seq* s, hipStream_t stream, uint8_t** stage, size_t* stage_bytes, int first, int count,
+                         const uint8_t* frames, int row_stride, int64_t frame_stride)
 {
-    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
-    GME_ENTER(s->ctx);
-    GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
-                "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
     const Plane& p = s->level[2];
     gme_ctx* ctx = s->ctx;
     if (row_stride == s->W && frame_stride == (int64_t)s->W * s->H && p.pitch != s->W && count > 0) {
@@ -480,33 +493,67 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
         size_t per = ((size_t)64 << 20) / frame_bytes;
         if (per < 1) per = 1;
         if (per > (size_t)count) per = (size_t)count;
-        if (per * frame_bytes > ctx->stage_bytes) {
-            GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (ctx->copy_stream) GME_HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
-            if (ctx->stage) hipFree(ctx->stage);
-            ctx->stage = nullptr; ctx->stage_bytes = 0;
-            if (hipMalloc((void**)&ctx->stage, per * frame_bytes) != hipSuccess) { gme_set_error("out of device memory (staging)"); return GME_ERR_NOMEM; }
-            ctx->stage_bytes = per * frame_bytes;
+        if (per * frame_bytes > *stage_bytes) {
+            GME_HIP_TRY(hipStreamSynchronize(stream));
+            if (ctx->copy_stream && stage == &ctx->stage) GME_HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+            if (*stage) hipFree(*stage);
+            *stage = nullptr; *stage_bytes = 0;
+            if (hipMalloc((void**)stage, per * frame_bytes) != hipSuccess) { gme_set_error("out of device memory (staging)"); return GME_ERR_NOMEM; }
+            *stage_bytes = per * frame_bytes;
         }
         for (int f0 = 0; f0 < count; f0 += (int)per) {
             const int n = count - f0 < (int)per ? count - f0 : (int)per;
-            GME_HIP_TRY(hipMemcpyAsync(ctx->stage, frames + (int64_t)f0 * frame_stride, (size_t)n * frame_bytes, hipMemcpyHostToDevice, ctx->stream));
-            int rc2 = launch_repack(ctx, ctx->stream, ctx->stage, n, s->H, s->W, p.at(first + f0), p.pitch, p.stride);
+            GME_HIP_TRY(hipMemcpyAsync(*stage, frames + (int64_t)f0 * frame_stride, (size_t)n * frame_bytes, hipMemcpyHostToDevice, stream));
+            int rc2 = launch_repack(ctx, stream, *stage, n, s->H, s->W, p.at(first + f0), p.pitch, p.stride);
             if (rc2) return rc2;
         }
     } else if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
         // planes and host frames are both back to back: one 2-D copy of count*H rows
         GME_HIP_TRY(hipMemcpy2DAsync(p.at(first), p.pitch, frames, row_stride, s->W, (size_t)s->H * count,
-                                     hipMemcpyHostToDevice, s->ctx->stream));
+                                     hipMemcpyHostToDevice, stream));
     } else {
         for (int i = 0; i < count; ++i)
             GME_HIP_TRY(hipMemcpy2DAsync(p.at(first + i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W,
-                                         s->H, hipMemcpyHostToDevice, s->ctx->stream));
+                                         s->H, hipMemcpyHostToDevice, stream));
     }
+    return GME_OK;
+}
+
+extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* frames, int row_stride,
+                              int64_t frame_stride)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    GME_ENTER(s->ctx);
+    GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
+                "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
+    gme_ctx* ctx = s->ctx;
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
     gme_drop_run(s);
-    GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));   // the host buffer may be reused on return
+    if (s->split_phase && ctx->device >= 0 && ctx->device < 16) {
+        // split-phase: the copies are queued and the call returns; `frames` must stay untouched until a later
+        // gme_seq_wait / gme_sync on this sequence has returned.  They run on the device's shared upload stream, behind
+        // whatever of this context still reads the planes (gate) and in front of whatever it queues next (s->uploaded);
+        // with page-locked frames (gme_host_alloc) the host thread is free at once and every context's kernels run beside the copy.
+        Uploader& u = g_uploader[ctx->device];
+        std::lock_guard<std::mutex> ulock(u.mu);
+        if (!u.stream) GME_HIP_TRY(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+        if (!s->upload_gate) {
+            GME_HIP_TRY(hipEventCreateWithFlags(&s->upload_gate, hipEventDisableTiming));
+            GME_HIP_TRY(hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
+        }
+        GME_HIP_TRY(hipEventRecord(s->upload_gate, ctx->stream));
+        GME_HIP_TRY(hipStreamWaitEvent(u.stream, s->upload_gate, 0));
+        int rc = upload_copies(s, u.stream, &u.stage, &u.stage_bytes, first, count, frames, row_stride, frame_stride);
+        if (rc) return rc;
+        GME_HIP_TRY(hipEventRecord(s->uploaded, u.stream));
+        GME_HIP_TRY(hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
+        GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
+        return GME_OK;
+    }
+    int rc = upload_copies(s, ctx->stream, &ctx->stage, &ctx->stage_bytes, first, count, frames, row_stride, frame_stride);
+    if (rc) return rc;
+    GME_HIP_TRY(hipStreamSynchronize(ctx->stream));      // the host buffer may be reused on return
     return GME_OK;
 }
 

@@ -5,7 +5,7 @@ parameters and the usages of the various scripts").  EXTENSION: the reference ha
 argparse scripts (bbme.py:658-714, results.py:117-138); their flags are kept as they are.
 
     python gme_cli.py bbme    -p <video|frame dir> -fi 13 -bs 16 -sw 16 -sp 0     # bbme.py main
-    python gme_cli.py results -v <name under resources/videos> -f 1 [--model affine]   # results.py main
+    python gme_cli.py results -v <name under resources/videos> -f 1 [--model similarity] [--suggest]   # results.py main
     python gme_cli.py suggest -p <video|frame dir> [-fi 1] [-f 1]                 # parameter heuristics
     python gme_cli.py info                                                          # searches, norms, models, device
 """
@@ -29,6 +29,11 @@ def _parser():
     r.add_argument("-f", "--frame-distance", dest="fd", type=str, required=False)
     r.add_argument("--block-size", type=int, default=None, help="motion.BBME_BLOCK_SIZE for this run (the authors patched the constant by hand)")
     r.add_argument("--outlier-fraction", type=float, default=None, help="motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE for this run")
+    r.add_argument("--model", choices=("affine", "translation", "similarity"), default="affine",
+                   help="motion model fitted per level (roadmap.solve_model); affine is the reference")
+    r.add_argument("--suggest", action="store_true",
+                   help="pick block size and outlier fraction for this video with roadmap.suggest_parameters (middle pair); "
+                        "explicit --block-size / --outlier-fraction win")
     s = sub.add_parser("suggest", help="heuristic block size / search window / outlier fraction for a frame pair (roadmap.suggest_parameters)")
     s.add_argument("-p", "--video-path", dest="path", type=str, required=True)
     s.add_argument("-fi", "--frame-index", dest="fi", type=int, default=1)
@@ -47,6 +52,17 @@ def main(argv=None):
         import results
         old = motion.BBME_BLOCK_SIZE, motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE
         try:
+            if args.suggest:
+                import os
+                import roadmap
+                import utils
+                frames = utils.get_video_frames(os.path.join("resources", "videos", args.path))
+                fd = int(args.fd) if args.fd is not None else results.FRAME_DISTANCE
+                mid = max(fd, len(frames) // 2)
+                hint = roadmap.suggest_parameters(frames[mid - fd], frames[mid])
+                print("suggested for this video: {}".format(hint))
+                motion.BBME_BLOCK_SIZE = hint["block_size"]
+                motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE = hint["outlier_fraction"]
             if args.block_size is not None:
                 motion.BBME_BLOCK_SIZE = args.block_size
             if args.outlier_fraction is not None:

@@ -124,6 +124,9 @@ def estimate_sequence(seq, frame_distance=1, procedure=3, search_window=2):
     Returns float64[P, 6].  Three device phases (begin, fit level 1, fit level 2) with the
     per-pair 3x3 solves on the host in between, exactly the order of motion.py:123-136.
     """
+    if getattr(seq, "_split", False):
+        raise RuntimeError("estimate_sequence needs blocking calls: the sequence is in split-phase mode "
+                           "(set_split_phase(False) first, or drive it with wait() like sequence._interleaved)")
     frac = float(MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
     params = seq.gme_begin(frame_distance, int(BBME_BLOCK_SIZE), procedure, search_window)   # float32[P,6]
     for level in (1, 2):

@@ -2,8 +2,8 @@
 
 Same outputs (five PNG sets and ``psnr_records.json`` with ``str(complex)`` values) and the same
 command line (``-v`` video name under ``resources/videos``, ``-f`` frame distance), but the
-video's pairs are estimated and compensated in one device-resident batch
-(``sequence.ShardedSequence``) instead of one pair at a time, and OpenCV is optional: frames may
+video's pairs stream through the device in chunks (``sequence.estimate_stream``: chunk k + 1 is uploaded
+while chunk k is estimated and compensated) instead of one pair at a time, and OpenCV is optional: frames may
 come from an image directory / ``.npy`` / ``.y4m`` (``utils.get_video_frames``) and PNGs are
 written with PIL when cv2 is missing.
 """
@@ -15,15 +15,18 @@ from json import dump
 import numpy as np
 
 import motion
-from sequence import ShardedSequence
+from sequence import estimate_stream
 from utils import draw_motion_field, get_video_frames, write_image
 
 FRAME_DISTANCE = 1          # results.py:11
-STREAMS = 3                 # HIP streams (pair ranges) per GPU: uploads run one host thread per range, the estimate one thread over all
+STREAMS = 3                 # lanes (context + HIP stream + chunk-sized device sequence) the chunks of a video rotate through
+CHUNK_PAIRS = 128           # pairs per chunk: 129 frames of 720x480 are 45 MB, under a millisecond on the link
 
 
-def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progress=False):
+def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progress=False, model="affine"):
     """results.py:41-112 for a list of grayscale frames -> ``{str(idx): str(psnr)}``.
+
+    ``model`` other than "affine" (the reference) selects one of roadmap.MODELS -- an extension, see roadmap.py.
 
     With ``save_path`` the five image sets are written with the reference's (quirky) names:
     ``frames/`` and ``compensated/`` use ``idx-5``, the others ``idx`` (results.py:64-106).
@@ -38,13 +41,16 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
     psnr_dict = {}
     if len(frames) <= fd:
         return psnr_dict
-    # a few streams per GPU: each lane uploads its range of the video in one copy and then works on it,
-    # so one lane's host->device copy runs beside the other lanes' kernels; the estimate is driven by one host
-    # thread over all streams (split-phase calls), whose 3x3 solves for one lane run beside the others' searches
-    seq = ShardedSequence(shape[0], shape[1], len(frames), fd, streams=STREAMS, interleave=True)
-    seq.load(frames)
-    params = seq.estimate()                                   # motion.global_motion_estimation per pair
-    psnr = seq.compensate(params)                             # compensate_frame + PSNR per pair
+    # the video stays in host memory and streams through a few lanes: one lane's upload runs beside the other lanes'
+    # kernels, one host thread drives all of them (split-phase calls) and does their 3x3 solves in between; every device
+    # object is released before this returns
+    n_pairs = len(frames) - fd
+    compensated_all = np.empty((n_pairs,) + tuple(shape), np.uint8) if save_path is not None else None
+    solve = None
+    if model != "affine":
+        import roadmap
+        solve = lambda sums: roadmap.solve_model(sums, model)       # noqa: E731
+    params, psnr = estimate_stream(frames, fd, chunk_pairs=CHUNK_PAIRS, streams=STREAMS, compensated=compensated_all, solve=solve)
     field_shape = (int(shape[0] / bs), int(shape[1] / bs), 2)
     for idx in range(fd, len(frames)):
         p = idx - fd
@@ -53,7 +59,7 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
             print("[%-20s] %d/%d frames" % ("=" * int(20 * j), idx, len(frames)))
         if save_path is not None:
             previous, current = frames[p], frames[idx]
-            compensated = seq.read_compensated(p)
+            compensated = compensated_all[p]
             model_motion_field = motion.get_motion_field_affine(field_shape, parameters=params[p])
             write_image(os.path.join(save_path, "frames", "") + str(idx - 5) + ".png", previous)
             write_image(os.path.join(save_path, "compensated", "") + str(idx - 5) + ".png", compensated)
@@ -87,7 +93,7 @@ def main(args):
         print("frame shape: {}".format(frames[0].shape))
     except Exception:
         raise Exception("Error reading video file: check the name of the video!")
-    return process_frames(frames, frame_distance, save_path, progress=True)
+    return process_frames(frames, frame_distance, save_path, progress=True, model=getattr(args, "model", None) or "affine")
 
 
 if __name__ == "__main__":

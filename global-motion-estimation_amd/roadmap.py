@@ -28,7 +28,6 @@ are opt-in and tested for self-consistency (``tests/test_gpu_round2.py``).
 """
 import numpy as np
 
-import _gme_native as _native
 import motion
 
 MODELS = ("affine", "translation", "similarity")
@@ -69,6 +68,8 @@ def solve_model(sums, model="affine"):
 
 def estimate_sequence(seq, frame_distance=1, model="affine", procedure=3, search_window=2):
     """motion.estimate_sequence with a selectable motion model -> float64[P, 6] (affine layout)."""
+    if getattr(seq, "_split", False):
+        raise RuntimeError("estimate_sequence needs blocking calls: the sequence is in split-phase mode")
     frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
     params = seq.gme_begin(frame_distance, int(motion.BBME_BLOCK_SIZE), procedure, search_window)
     for level in (1, 2):
@@ -80,11 +81,7 @@ def estimate_sequence(seq, frame_distance=1, model="affine", procedure=3, search
 
 def global_motion_estimation(previous, current, model="affine"):
     """motion.global_motion_estimation (motion.py:109-136) with a selectable model."""
-    seq = _native.Sequence.from_frames(_native.default_context(), [previous, current])
-    try:
-        return estimate_sequence(seq, 1, model)[0]
-    finally:
-        seq.close()
+    return estimate_sequence(motion._pair_sequence(previous, current), 1, model)[0]      # the cached two-frame sequence of motion.py
 
 
 def suggest_parameters(previous, current):

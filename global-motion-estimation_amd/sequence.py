@@ -266,6 +266,26 @@ def gather_parameters_rccl(ctx, local, n_pairs, rank, world):
     return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
 
 
+def psnr_from_sse(sse, height, width, exact=True):
+    """utils.PSNR (utils.py:100-116) from sums of squared error: -1 where the frames are equal,
+    else the real part of the reference's complex 20 log10(255 / sqrt(mse)).
+
+    ``exact`` evaluates it per pair with cmath like the reference (results.py writes
+    ``str(value)`` into psnr_records.json, so the last bit shows); the vectorised NumPy form
+    differs from it by at most 2e-14 dB and is what the batch hot path uses."""
+    mse = np.asarray(sse, dtype=np.float64) / (height * width)
+    out = np.full(len(mse), -1.0)
+    if exact:
+        from cmath import log10, sqrt
+        for k, m in enumerate(mse):
+            if m != 0:
+                out[k] = (20 * log10(255.0 / sqrt(m))).real
+        return out
+    nz = mse != 0
+    out[nz] = 20.0 * np.log10(255.0 / np.sqrt(mse[nz]))
+    return out
+
+
 class _Lane:
     """One stream's part of a shard: its own context (HIP stream) and resident frames."""
 
@@ -386,23 +406,7 @@ class ShardedSequence:
             lambda lane: motion.estimate_sequence(lane.seq, self.fd, procedure, search_window)[:lane.hi - lane.lo]), axis=0)
 
     def _psnr(self, sse, exact=True):
-        """utils.PSNR (utils.py:100-116) from sums of squared error: -1 where the frames are equal,
-        else the real part of the reference's complex 20 log10(255 / sqrt(mse)).
-
-        ``exact`` evaluates it per pair with cmath like the reference (results.py writes
-        ``str(value)`` into psnr_records.json, so the last bit shows); the vectorised NumPy form
-        differs from it by at most 2e-14 dB and is what the batch hot path uses."""
-        mse = np.asarray(sse, dtype=np.float64) / (self.H * self.W)
-        out = np.full(len(mse), -1.0)
-        if exact:
-            from cmath import log10, sqrt
-            for k, m in enumerate(mse):
-                if m != 0:
-                    out[k] = (20 * log10(255.0 / sqrt(m))).real
-            return out
-        nz = mse != 0
-        out[nz] = 20.0 * np.log10(255.0 / np.sqrt(mse[nz]))
-        return out
+        return psnr_from_sse(sse, self.H, self.W, exact)
 
     def compensate(self, params):
         """results.py:52-59,109 for every local pair -> PSNR(current, compensated) as float64[P_local]."""
@@ -481,3 +485,120 @@ class ShardedSequence:
         """float64[world, n_max, k] blocks of a fixed-size all-gather -> float64[P_total, k]."""
         _, sizes = pad_and_trim(self.n_pairs_total, self.world)
         return np.concatenate([gathered[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
+
+
+def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=3, ctx=None, compensated=None, procedure=3,
+                    search_window=2, exact_psnr=True, solve=None):
+    """results.py:41-59,109 for a video that still lives in HOST memory -> (params float64[P, 6], psnr float64[P]).
+
+    The video is cut into chunks of ``chunk_pairs`` pairs (plus the ``fd`` halo frames); ``streams`` lanes -- each its own
+    context, HIP stream and (chunk_pairs + fd)-frame device sequence -- take the chunks in turn.  Everything a lane does
+    is split-phase (gme_seq_set_split_phase): upload of its chunk, pyramids + dense field, level fits, compensation are
+    queued on the lane's stream and ONE host thread visits the lanes round robin, awaiting a lane's last result, doing
+    its projection / 3x3 solves (motion.py:191-207,262-282) and queueing its next stage.  While one lane's frames cross
+    the link the other lanes' kernels run, so a video larger than HBM streams through at link speed.
+
+    ``frames``: uint8[N, H, W] (page-locked memory from _gme_native.pinned_empty crosses at link speed and never holds
+    the host thread) or a list of 2-D uint8 arrays (gathered chunk by chunk into a page-locked buffer per lane).
+    ``compensated``: optional uint8[P, H, W] array that receives every compensated frame (results.py:59 writes them out).
+    ``solve``: float64[n, 15] normal-equation sums -> float64[n, 6] parameters; default motion._solve_batch (the
+    reference's two 3x3 systems), roadmap.solve_model for the other motion models.
+    Results equal the resident path bit for bit (tests/test_gpu_round3.py)."""
+    fd = int(frame_distance)
+    n_frames = len(frames)
+    first = np.asarray(frames[0])
+    H, W = first.shape
+    P = max(0, n_frames - fd)
+    params_out, sse_out = np.zeros((P, 6)), np.zeros(P, dtype=np.int64)
+    if P == 0:
+        return params_out, np.zeros(0)
+    chunk_pairs = max(1, min(int(chunk_pairs), P))
+    chunks = [(p0, min(p0 + chunk_pairs, P)) for p0 in range(0, P, chunk_pairs)]
+    ctx0 = ctx or _native.default_context()
+    stacked = isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
+    frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
+    bs = int(motion.BBME_BLOCK_SIZE)
+    cap = chunk_pairs + fd                       # frames a lane holds
+    solve = solve or motion._solve_batch
+
+    class Job:
+        """One lane and the chunk it is working on; advance() waits for the lane's last result and queues the next stage."""
+
+        def __init__(self, c):
+            self.ctx = c
+            self.seq = _native.Sequence(c, cap, H, W)
+            self.seq.set_split_phase(True)
+            self.host = None if stacked else _native.pinned_empty((cap, H, W))
+            self.chunk, self.stage, self.pending, self.params = None, 0, None, None
+
+        def start(self, chunk):
+            self.chunk, self.stage = chunk, 1
+            p0, p1 = chunk
+            n = p1 - p0 + fd
+            if stacked:
+                src = frames[p0:p0 + n]
+            else:
+                for k in range(n):
+                    self.host[k] = frames[p0 + k]
+                src = self.host[:n]
+            self.seq.upload(0, src)              # queued; `src` stays alive (self.host / the caller's array)
+            self.pending = self.seq.gme_begin(fd, bs, procedure, search_window)
+
+        def advance(self):
+            """-> True when the chunk is finished (the lane is free again)."""
+            seq, (p0, p1) = self.seq, self.chunk
+            n = p1 - p0
+            seq.wait()
+            if self.stage in (1, 2):
+                level = self.stage
+                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64;
+                # rows behind the chunk's pairs belong to stale frames of an earlier chunk: carried along as zeros
+                p = np.array(self.pending[:n]) if level == 1 else solve(self.pending[:n])
+                p[:, 0] = p[:, 0] * 2
+                p[:, 3] = p[:, 3] * 2
+                full = np.zeros((cap - fd, 6))
+                full[:n] = p
+                self.pending = seq.gme_fit(level, full, frac)
+                self.stage += 1
+                return False
+            if self.stage == 3:
+                self.params = solve(self.pending[:n])
+                full = np.zeros((cap - fd, 6))
+                full[:n] = self.params
+                self.pending = seq.compensate(fd, bs, full)
+                self.stage = 4
+                return False
+            params_out[p0:p1] = self.params
+            sse_out[p0:p1] = self.pending[:n]
+            self.ctx.sync()                      # drains the lane and reports a walk that overran its guard
+            if compensated is not None:
+                for k in range(n):
+                    compensated[p0 + k] = seq.read_compensated(k)
+            self.stage = 0
+            return True
+
+        def close(self):
+            self.seq.set_split_phase(False)
+            self.seq.close()
+            if self.ctx is not ctx0:
+                self.ctx.close()
+
+    jobs = [Job(ctx0 if j == 0 else _native.Context(ctx0.device)) for j in range(max(1, min(int(streams), len(chunks))))]
+    try:
+        todo = list(reversed(chunks))
+        busy = []
+        for job in jobs:
+            if todo:
+                job.start(todo.pop())
+                busy.append(job)
+        while busy:
+            for job in list(busy):
+                if job.advance():
+                    if todo:
+                        job.start(todo.pop())
+                    else:
+                        busy.remove(job)
+    finally:
+        for job in jobs:
+            job.close()
+    return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)

@@ -174,7 +174,9 @@ GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
  * gme_seq_gme_begin / gme_seq_gme_fit / gme_seq_compensate return as soon as their work is queued; their output
  * buffer (page-locked: gme_host_alloc) is valid after gme_seq_wait, which waits for the result of the last such call
  * only -- the level search queued behind it keeps running.  gme_sync still drains the stream and reports walk
- * overruns. */
+ * overruns.  gme_seq_upload is split-phase too: it returns with its copies queued on the context's stream, and the
+ * host frames must stay untouched until a later gme_seq_wait / gme_sync returns -- how sequence.estimate_stream keeps the
+ * link busy with chunk k + 1 of a video in host memory (results.py:41-50, utils.py:9-31) while chunk k is estimated. */
 GME_API int gme_seq_set_split_phase(gme_seq *seq, int on);
 GME_API int gme_seq_wait(gme_seq *seq);
 
