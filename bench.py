@@ -760,6 +760,35 @@ def measure(opt, ctx, comm, rank, world):
                                  "note": "gme_seq_bbme_streamed: %d frames from page-locked host memory uploaded in chunks on a copy stream "
                                          "while the previous chunk is searched, + read-back of %d fields; each frame crosses the link once "
                                          "(from_pageable_memory: the same call on an ordinary NumPy array)" % (n_e2e + 1, n_e2e)}
+    if proc == -1 and world == 1 and opt.pcie:
+        # the same flow from frames in HOST memory (results.py:41-59 hands the path host arrays): sequence.StreamEstimator
+        # uploads chunk k + 1 while chunk k is estimated and compensated; NOT `value`
+        import sequence
+        chunk = int(os.environ.get("GME_BENCH_CHUNK", "128"))
+        lanes_e = int(os.environ.get("GME_BENCH_STREAM_LANES", "2"))
+        host_frames = native.pinned_empty((B + 1, H, W))
+        for lane in shard.lanes:
+            for k in range(lane.hi - lane.lo + 1):
+                host_frames[lane.lo + k] = lane.seq.read_frame(k)
+        with sequence.StreamEstimator(H, W, 1, chunk, lanes_e, ctx=ctx) as est:
+            est.run(host_frames, exact_psnr=False)                       # first touch
+            t_e = time.perf_counter()
+            p_e, psnr_e = est.run(host_frames, exact_psnr=False)
+            t_e = time.perf_counter() - t_e
+        seq2 = native.Sequence(ctx, B + 1, H, W)
+        seq2.upload(0, host_frames)
+        t_c = time.perf_counter()                                        # the copy alone (same bytes, page-locked source): the ceiling
+        seq2.upload(0, host_frames)
+        t_c = time.perf_counter() - t_c
+        seq2.close()
+        out["pcie_inclusive"] = {"value": B / t_e, "unit": "frame-pairs/s", "chunk_pairs": chunk, "lanes": lanes_e,
+                                 "equals_resident_result": bool(np.array_equal(p_e, last["params"]) and np.array_equal(psnr_e, last["psnr"])),
+                                 "host_to_device_GBps": (B + 1) * H * W / t_e / 1e9,
+                                 "copy_only": {"GBps": (B + 1) * H * W / t_c / 1e9, "pairs_per_s_if_nothing_else": B / t_c},
+                                 "fraction_of_copy_ceiling": t_c / t_e,
+                                 "note": "sequence.StreamEstimator: %d frames from page-locked host memory in chunks of %d pairs over %d lanes "
+                                         "(split-phase uploads on one shared upload stream, estimate + compensation + PSNR per chunk); "
+                                         "parameters and PSNR read back, compensated frames stay on the device" % (B + 1, chunk, lanes_e)}
     if proc == -3:
         rows = last["rows"]
         out["sequence"] = {"pairs_total": int(shard.n_pairs_total), "gathered_rows": int(rows.shape[0]),

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
     "gme_seq_set_split_phase": (_i, [_vp, _i]),
     "gme_seq_wait": (_i, [_vp]),
+    "gme_seq_poll": (_i, [_vp]),
 }
 
 _lib = None
@@ -423,6 +424,13 @@ class Sequence:
 
     def wait(self):
         _check(self.lib.gme_seq_wait(self.handle), self.lib)
+
+    def poll(self):
+        """True when wait() would return at once (the last split-phase result has arrived)."""
+        rc = self.lib.gme_seq_poll(self.handle)
+        if rc < 0:
+            _raise(rc, self.lib)
+        return rc == 1
 
     def _buffer(self, name, shape, dtype):
         """Result / argument array of a staged call: ordinary memory, or (split-phase) one page-locked block per

@@ -396,10 +396,12 @@ __global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
         const int trow = wg / r.tile_wg_per_row, bcol0 = (wg - trow * r.tile_wg_per_row) * d.nb;
         const int pair = lp * 8 + xcd, brow = trow * r.tr + row_in_tile;
         const bool ok = brow < d.nbr && pair < d.pairs;                                     // ragged last tile row
-        // everything derived from the thread index is recomputed per item from an opaque copy: hoisted out of the work loop
-        // those values (window offsets, table addresses) cost ~45 VGPRs in the MSE body (112 against the 66 of k_exh_dot16)
+        // MSE: everything derived from the thread index is recomputed per item from an opaque copy -- hoisted out of the
+        // work loop those values (window offsets, table addresses) cost ~20 VGPRs in the MSE body (112 -> 91: 4 -> 5 waves
+        // per SIMD, +2.8 % on noise).  The MAE body is better off with the hoisting (72 VGPRs either way 7 waves; 9 scalar
+        // spills and -1.8 % with the opaque copy).
         int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        if (MSE) asm volatile("" : "+v"(tid));
         if (ok) stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16, tid);
         __syncthreads();
         if (ok) {
@@ -410,8 +412,8 @@ __global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
     }
 }
 
-// 16x16 box sums of squares of one plane stack in ONE pass (4 bytes of HBM traffic per pixel: 1 read, 3 written;
-// round 2 wrote uint32 sums, 5 bytes per pixel, and this kernel was 15 % of the exhaustive MSE step).
+// 16x16 box sums of squares of one plane stack in ONE pass (5.5 bytes of HBM traffic per pixel
+// instead of the ~15 of a rows pass + a columns pass through a uint32 scratch plane).
 // Thread -> four adjacent columns x .. x+3 (x % 4 == 0) of a chunk of SQ_CHUNK output rows:
 //   h(row) = the four horizontal 16-byte sums of squares of `row`: five aligned dwords, three
 //            v_alignbyte copies of each, sixteen v_dot4(b, b);
@@ -448,9 +450,7 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SQ_CHUNK;
     if (x > W - 16 || y0 > H - 16) return;
     const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y0 * pitch + x;
-    const SqTable tab = sq_table(dst + (long long)blockIdx.z * dst_stride, H, pitch);
-    uint16_t* olo = (uint16_t*)tab.lo + (long long)y0 * pitch + x;
-    uint8_t* ohi = (uint8_t*)tab.hi + (long long)y0 * pitch + x;
+    uint32_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y0 * pitch + x;
     u32x4_v ring[16], s = { 0, 0, 0, 0 };
 #pragma unroll
     for (int r = 0; r < 15; ++r) {                       // rows y0 .. y0+14 <= H-2
@@ -465,11 +465,7 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
             if (k <= last) {
                 const u32x4_v h = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);   // row y0+k+15 <= H-1
                 s += h;
-                // 24-bit sums (16 * 16 * 255^2 < 2^24) as a 16-bit and an 8-bit plane: 3 bytes per position, aligned 8- and 4-byte stores
-                const uint32_t l01 = __builtin_amdgcn_perm(s.y, s.x, 0x05040100u), l23 = __builtin_amdgcn_perm(s.w, s.z, 0x05040100u);
-                const uint32_t h8 = __builtin_amdgcn_perm(s.y, s.x, 0x0C0C0602u) | (__builtin_amdgcn_perm(s.w, s.z, 0x0C0C0602u) << 16);
-                *(uint2*)(olo + (long long)k * pitch) = make_uint2(l01, l23);
-                *(uint32_t*)(ohi + (long long)k * pitch) = h8;
+                *(u32x4_v*)(o + (long long)k * pitch) = s;
                 s -= ring[u];                            // h(y0 + k): row r lives in ring[r & 15]
                 ring[(u + 15) & 15] = h;
             }

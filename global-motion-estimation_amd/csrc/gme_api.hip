@@ -458,6 +458,20 @@ extern "C" int gme_seq_wait(gme_seq* s)
     return GME_OK;
 }
 
+// 1 when the result of the last split-phase call has arrived (gme_seq_wait would return at once), 0 when it is still
+// on its way: lets one host thread serve whichever of several sequences is ready first instead of blocking on one.
+extern "C" int gme_seq_poll(gme_seq* s)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    GME_ENTER(s->ctx);
+    GME_REQUIRE(s->ready != nullptr, GME_ERR_STATE, "gme_seq_poll without gme_seq_set_split_phase");
+    const hipError_t e = hipEventQuery(s->ready);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    gme_set_error("hipEventQuery failed: %s", hipGetErrorString(e));
+    return GME_ERR_HIP;
+}
+
 // new frame data ends a staged GME run: searches gme_seq_gme_begin deferred must not see other frames
 // than the stages already done, so the run is dropped (gme_seq_gme_fit then asks for a new begin)
 static void gme_drop_run(gme_seq* s)

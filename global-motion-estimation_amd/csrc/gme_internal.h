@@ -136,35 +136,26 @@ struct BbmeJob {
     int H, W, pitch;
     int bs, sw, procedure, pnorm;
     int32_t* mf;                  // [pairs][H/bs][W/bs][2]
-    const uint32_t* sqbox_cur;    // optional, matches `cur` planes: one SqTable slot (4 * stride bytes) per plane
+    const uint32_t* sqbox_cur;    // optional, matches `cur` planes: [pairs][H][pitch] uint32 (SqTable)
     int64_t sqbox_stride;         // elements between consecutive planes
     bool chained = false;         // a later chunk of one streamed call: keep the plan text and the statistics
 };
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
 int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int tile_wg_per_row, int tile_wg_per_pair,
                     const uint32_t* list, const uint32_t* count, uint32_t* head);
-// The table of 16x16 box sums of squares (exhaustive MSE, bs 16) keeps its 24-bit values (16 * 16 * 255^2 < 2^24) as two
-// planes inside each frame's slot of 4 * stride bytes: uint16 low halves [H][pitch] at byte 0, uint8 high bytes [H][pitch]
-// at byte 2 * H * pitch.  Positions are those of the frame (row * pitch + column); rows > H - 16 and columns > W - 16 hold
-// nothing.  The four positions x .. x+3 of a row (x % 4 == 0) come with one 8-byte and one 4-byte read.
+// The table of 16x16 box sums of squares (exhaustive MSE, bs 16): uint32 [H][pitch] per frame, positions are those of the
+// frame (row * pitch + column); rows > H - 16 and columns > W - 16 hold nothing.  The four positions x .. x+3 of a row
+// (x % 4 == 0) come with one 16-byte read.  (A 24-bit layout -- 16-bit and 8-bit planes, 3 instead of 4 bytes per position --
+// was tried in round 3: the table kernel's two narrower stores per row made IT 17 % slower, 1.43 against 1.22 ms per 2049
+// frames of 720x480, and the whole MSE search 4 %.)
 #ifdef __HIPCC__
-struct SqTable { const uint16_t* lo; const uint8_t* hi; };
-__device__ __forceinline__ SqTable sq_table(const uint32_t* slot, int H, int pitch)
+typedef const uint32_t* SqTable;
+__device__ __forceinline__ SqTable sq_table(const uint32_t* slot, int, int) { return slot; }
+__device__ __forceinline__ uint32_t sq1(SqTable t, long long idx) { return t[idx]; }
+__device__ __forceinline__ void sq4(SqTable t, long long idx, uint32_t (&out)[4])       // idx % 4 == 0
 {
-    SqTable t;
-    t.lo = (const uint16_t*)slot;
-    t.hi = (const uint8_t*)slot + 2ll * H * pitch;
-    return t;
-}
-__device__ __forceinline__ uint32_t sq1(const SqTable& t, long long idx) { return (uint32_t)t.lo[idx] | ((uint32_t)t.hi[idx] << 16); }
-__device__ __forceinline__ void sq4(const SqTable& t, long long idx, uint32_t (&out)[4])       // idx % 4 == 0
-{
-    const uint2 l = *(const uint2*)(t.lo + idx);
-    const uint32_t h = *(const uint32_t*)(t.hi + idx);
-    out[0] = __builtin_amdgcn_perm(h, l.x, 0x0C040100u);
-    out[1] = __builtin_amdgcn_perm(h, l.x, 0x0C050302u);
-    out[2] = __builtin_amdgcn_perm(h, l.y, 0x0C060100u);
-    out[3] = __builtin_amdgcn_perm(h, l.y, 0x0C070302u);
+    const uint4 v = *(const uint4*)(t + idx);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 #endif
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,

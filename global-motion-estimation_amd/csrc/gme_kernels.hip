@@ -85,6 +85,92 @@ __global__ void __launch_bounds__(256) k_pyrdown(const uint8_t* src, long long s
     if (two) *(uint32_t*)(o + dpitch) = out1;
 }
 
+// One launch per level for planes whose width is a multiple of 8 (every level of the BASELINE shapes): a workgroup
+// stages the 2 T + 3 source rows of T output rows in LDS -- rows reflected (BORDER_REFLECT_101) when it picks them,
+// the two border columns on each side written into an apron behind the barrier -- so every output quad, border ones
+// included, runs the interior arithmetic of k_pyrdown on LDS reads.  No border launch (k_pyrdown_edge16 was a quarter
+// of the pyramid's time for 2 % of its pixels), each source byte crosses HBM once (+ 3 halo rows per 16).
+constexpr int PYR_T = 8;                       // output rows per workgroup
+constexpr int PYR_ROWS = 2 * PYR_T + 3;        // source rows staged
+constexpr int PYR_APRON = 4;                   // pixel 0 sits at byte 4 of an LDS row: quad x reads bytes 2x .. 2x+15 (8-byte aligned)
+
+__global__ void __launch_bounds__(256) k_pyrdown_lds(const uint8_t* src, long long src_stride, int sH, int sW, int spitch,
+                                                      uint8_t* dst, long long dst_stride, int dH, int dW, int dpitch, int lpitch,
+                                                      uint32_t magic_row, uint32_t magic_quads)
+{
+    extern __shared__ uint32_t pyr_lds[];
+    uint8_t* rows = (uint8_t*)pyr_lds;         // [PYR_ROWS][lpitch], lpitch % 8 == 0
+    const int y0 = blockIdx.y * PYR_T;
+    const uint8_t* s = src + (long long)blockIdx.z * src_stride;
+    // ---- stage: 16-byte segments, source row r of the tile = reflect101(2 y0 - 2 + r); four loads in flight per thread,
+    // index -> (row, segment) by a multiply-shift (magic_row = 2^20 / per_row + 1: exact below 4096 items)
+    const int segs = sW >> 4, tail = sW & 15;   // sW % 8 == 0: an 8-byte tail segment when sW % 16 == 8
+    const int per_row = segs + (tail ? 1 : 0);
+    const int total = PYR_ROWS * per_row;
+    for (int base = threadIdx.x; base < total; base += 4 * 256) {
+        u32x4_a4 v[4];
+        int off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = base + 256 * u;
+            const int r = (int)(__umul24((uint32_t)it, magic_row) >> 20), sg = it - r * per_row;
+            off[u] = -1;
+            v[u] = u32x4_a4{ 0, 0, 0, 0 };
+            if (it < total) {
+                const uint8_t* g = s + (long long)reflect101(2 * y0 - 2 + r, sH) * spitch + 16 * sg;
+                off[u] = r * lpitch + PYR_APRON + 16 * sg + (sg < segs ? 0 : 1);      // odd: the 8-byte tail segment
+                if (sg < segs) v[u] = *(const u32x4_a4*)g;
+                else { const uint2 t = *(const uint2*)g; v[u].x = t.x; v[u].y = t.y; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (off[u] >= 0) {
+                uint32_t* l = (uint32_t*)(rows + (off[u] & ~1));
+                l[0] = v[u].x; l[1] = v[u].y;
+                if (!(off[u] & 1)) { l[2] = v[u].z; l[3] = v[u].w; }
+            }
+    }
+    __syncthreads();
+    // ---- aprons: columns -2, -1 = 2, 1 and sW, sW + 1 = sW - 2, sW - 3 (reflect101; sW >= 8)
+    if (threadIdx.x < PYR_ROWS * 4) {
+        const int r = threadIdx.x >> 2, k = threadIdx.x & 3;
+        uint8_t* row = rows + r * lpitch + PYR_APRON;
+        const int to = k == 0 ? -2 : k == 1 ? -1 : k == 2 ? sW : sW + 1;
+        const int from = k == 0 ? 2 : k == 1 ? 1 : k == 2 ? sW - 2 : sW - 3;
+        row[to] = row[from];
+    }
+    __syncthreads();
+    // ---- compute: item = (row pair, quad); the arithmetic of k_pyrdown
+    const int quads = dW >> 2;                  // dW = sW / 2 is a multiple of 4
+    for (int it = threadIdx.x; it < (PYR_T / 2) * quads; it += 256) {
+        const int rp = (int)(__umul24((uint32_t)it, magic_quads) >> 20), qx = it - rp * quads;
+        const int y = y0 + 2 * rp;
+        if (y >= dH) break;                     // items are row-major: everything behind is outside too
+        const uint8_t* l = rows + (4 * rp) * lpitch + 8 * qx;        // byte 2x - 4 + PYR_APRON of tile row 4 rp, x = 4 qx
+        int h[7][4];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const uint2 lo = *(const uint2*)(l + r * lpitch), hi = *(const uint2*)(l + r * lpitch + 8);
+            const uint32_t w4[4] = { __builtin_amdgcn_alignbyte(lo.y, lo.x, 2u), lo.y, __builtin_amdgcn_alignbyte(hi.x, lo.y, 2u), hi.x };
+            const uint32_t last[4] = { (lo.y >> 16) & 0xFFu, hi.x & 0xFFu, (hi.x >> 16) & 0xFFu, hi.y & 0xFFu };
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[r][p] = (int)__builtin_amdgcn_udot4(w4[p], 0x04060401u, last[p], false);
+        }
+        uint32_t out0 = 0, out1 = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int a0 = h[0][p] + 4 * h[1][p] + 6 * h[2][p] + 4 * h[3][p] + h[4][p];
+            const int a1 = h[2][p] + 4 * h[3][p] + 6 * h[4][p] + 4 * h[5][p] + h[6][p];
+            out0 |= (uint32_t)((a0 + 128) >> 8) << (8 * p);
+            out1 |= (uint32_t)((a1 + 128) >> 8) << (8 * p);
+        }
+        uint8_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y * dpitch + 4 * qx;
+        *(uint32_t*)o = out0;
+        if (y + 1 < dH) *(uint32_t*)(o + dpitch) = out1;
+    }
+}
+
 // border pixels: x in [0, 4) and [x_end, dW); one thread per pixel
 __global__ void __launch_bounds__(256) k_pyrdown_edge(const uint8_t* src, long long src_stride, int sH, int sW,
                                                        int spitch, uint8_t* dst, long long dst_stride, int dH,
@@ -673,6 +759,22 @@ int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst)
     const int interior_quads = (x_end - 4) / 4;
     const int per_row = (dst.W < 4 ? dst.W : 4) + (dst.W - x_end > 0 ? dst.W - x_end : 0);
     const int step = max_grid_planes();
+    // LDS-tiled form: widths that are multiples of 8 (output quads, 8-byte LDS reads) and fit the 64 KB of a workgroup
+    const int lpitch = (PYR_APRON + src.W + 2 + 7) & ~7;
+    const size_t lds = (size_t)PYR_ROWS * lpitch;
+    const int pyr_per_row = (src.W + 15) / 16, pyr_quads = dst.W / 4;
+    if (src.W % 8 == 0 && src.W >= 8 && src.pitch % 16 == 0 && lds <= 64 * 1024 && PYR_ROWS * pyr_per_row < 4096 && pyr_per_row < 256 &&
+        (PYR_T / 2) * pyr_quads < 4096 && pyr_quads < 256 && !getenv("GME_FORCE_GENERIC") && !getenv("GME_PYR_NOLDS")) {
+        const uint32_t magic_row = (1u << 20) / (uint32_t)pyr_per_row + 1u, magic_quads = (1u << 20) / (uint32_t)pyr_quads + 1u;
+        for (int first = 0; first < src.count; first += step) {
+            const int n = src.count - first < step ? src.count - first : step;
+            hipLaunchKernelGGL(k_pyrdown_lds, dim3(1, (dst.H + PYR_T - 1) / PYR_T, n), dim3(256), lds, ctx->stream, src.at(first),
+                               (long long)src.stride, src.H, src.W, src.pitch, dst.at(first), (long long)dst.stride, dst.H, dst.W,
+                               dst.pitch, lpitch, magic_row, magic_quads);
+        }
+        GME_HIP_TRY(hipGetLastError());
+        return GME_OK;
+    }
     for (int first = 0; first < src.count; first += step) {            // grid.z holds at most 65535 planes
         const int n = src.count - first < step ? src.count - first : step;
         if (interior_quads > 0) {

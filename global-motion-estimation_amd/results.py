@@ -19,7 +19,7 @@ from sequence import estimate_stream
 from utils import draw_motion_field, get_video_frames, write_image
 
 FRAME_DISTANCE = 1          # results.py:11
-STREAMS = 3                 # lanes (context + HIP stream + chunk-sized device sequence) the chunks of a video rotate through
+STREAMS = 2                 # lanes (context + HIP stream + chunk-sized device sequence) the chunks of a video rotate through
 CHUNK_PAIRS = 128           # pairs per chunk: 129 frames of 720x480 are 45 MB, under a millisecond on the link
 
 

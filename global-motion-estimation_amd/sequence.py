@@ -15,6 +15,7 @@ import ctypes
 import os
 import stat
 import time
+import types
 
 import numpy as np
 
@@ -487,16 +488,16 @@ class ShardedSequence:
         return np.concatenate([gathered[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
 
 
-def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=3, ctx=None, compensated=None, procedure=3,
-                    search_window=2, exact_psnr=True, solve=None):
-    """results.py:41-59,109 for a video that still lives in HOST memory -> (params float64[P, 6], psnr float64[P]).
+class StreamEstimator:
+    """results.py:41-59,109 for videos that still live in HOST memory: ``run(frames)`` -> (params float64[P, 6], psnr float64[P]).
 
-    The video is cut into chunks of ``chunk_pairs`` pairs (plus the ``fd`` halo frames); ``streams`` lanes -- each its own
-    context, HIP stream and (chunk_pairs + fd)-frame device sequence -- take the chunks in turn.  Everything a lane does
-    is split-phase (gme_seq_set_split_phase): upload of its chunk, pyramids + dense field, level fits, compensation are
-    queued on the lane's stream and ONE host thread visits the lanes round robin, awaiting a lane's last result, doing
-    its projection / 3x3 solves (motion.py:191-207,262-282) and queueing its next stage.  While one lane's frames cross
-    the link the other lanes' kernels run, so a video larger than HBM streams through at link speed.
+    A video is cut into chunks of ``chunk_pairs`` pairs (plus the ``fd`` halo frames); ``streams`` lanes -- each its own
+    context, HIP stream and (chunk_pairs + fd)-frame device sequence, allocated once here and reused by every run() --
+    take the chunks in turn.  Everything a lane does is split-phase (gme_seq_set_split_phase): the upload of its chunk
+    (on the device's shared upload stream), pyramids + dense field, level fits, compensation are queued and ONE host
+    thread serves whichever lane has its result (gme_seq_poll), doing its projection / 3x3 solves (motion.py:191-207,
+    262-282) and queueing its next stage.  While one lane's frames cross the link the other lanes' kernels run, so a
+    video larger than HBM streams through at link speed.
 
     ``frames``: uint8[N, H, W] (page-locked memory from _gme_native.pinned_empty crosses at link speed and never holds
     the host thread) or a list of 2-D uint8 arrays (gathered chunk by chunk into a page-locked buffer per lane).
@@ -504,101 +505,145 @@ def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=3, ctx=No
     ``solve``: float64[n, 15] normal-equation sums -> float64[n, 6] parameters; default motion._solve_batch (the
     reference's two 3x3 systems), roadmap.solve_model for the other motion models.
     Results equal the resident path bit for bit (tests/test_gpu_round3.py)."""
-    fd = int(frame_distance)
-    n_frames = len(frames)
-    first = np.asarray(frames[0])
-    H, W = first.shape
-    P = max(0, n_frames - fd)
-    params_out, sse_out = np.zeros((P, 6)), np.zeros(P, dtype=np.int64)
-    if P == 0:
-        return params_out, np.zeros(0)
-    chunk_pairs = max(1, min(int(chunk_pairs), P))
-    chunks = [(p0, min(p0 + chunk_pairs, P)) for p0 in range(0, P, chunk_pairs)]
-    ctx0 = ctx or _native.default_context()
-    stacked = isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
-    frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
-    bs = int(motion.BBME_BLOCK_SIZE)
-    cap = chunk_pairs + fd                       # frames a lane holds
-    solve = solve or motion._solve_batch
 
-    class Job:
-        """One lane and the chunk it is working on; advance() waits for the lane's last result and queues the next stage."""
+    def __init__(self, height, width, frame_distance=1, chunk_pairs=128, streams=2, ctx=None, procedure=3, search_window=2):
+        self.H, self.W, self.fd = int(height), int(width), int(frame_distance)
+        self.chunk_pairs = max(1, int(chunk_pairs))
+        self.cap = self.chunk_pairs + self.fd                    # frames a lane holds
+        self.procedure, self.search_window = procedure, search_window
+        self.ctx = ctx or _native.default_context()
+        self.lanes = []
+        try:
+            for j in range(max(1, int(streams))):
+                c = self.ctx if j == 0 else _native.Context(self.ctx.device)
+                seq = _native.Sequence(c, self.cap, self.H, self.W)
+                seq.set_split_phase(True)
+                self.lanes.append(types.SimpleNamespace(ctx=c, seq=seq, host=None, chunk=None, stage=0, pending=None, params=None))
+        except BaseException:
+            self.close(check=False)
+            raise
 
-        def __init__(self, c):
-            self.ctx = c
-            self.seq = _native.Sequence(c, cap, H, W)
-            self.seq.set_split_phase(True)
-            self.host = None if stacked else _native.pinned_empty((cap, H, W))
-            self.chunk, self.stage, self.pending, self.params = None, 0, None, None
+    def close(self, check=True):
+        """Release the lanes' device objects; with ``check`` a walk that overran its guard is reported (gme_sync)."""
+        lanes, self.lanes = self.lanes, []
+        err = None
+        for lane in lanes:
+            try:
+                lane.seq.set_split_phase(False)
+                if check:
+                    lane.ctx.sync()
+            except Exception as e:                                   # noqa: BLE001 -- release everything, then report
+                err = err or e
+            finally:
+                lane.seq.close()
+                if lane.ctx is not self.ctx:
+                    lane.ctx.close()
+        if err is not None and check:
+            raise err
 
-        def start(self, chunk):
-            self.chunk, self.stage = chunk, 1
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close(check=exc[0] is None)
+
+    def run(self, frames, compensated=None, exact_psnr=True, solve=None):
+        fd, H, W, cap = self.fd, self.H, self.W, self.cap
+        P = max(0, len(frames) - fd)
+        params_out, sse_out = np.zeros((P, 6)), np.zeros(P, dtype=np.int64)
+        if P == 0:
+            return params_out, np.zeros(0)
+        if tuple(np.asarray(frames[0]).shape) != (H, W):
+            raise ValueError("frames of %r do not fit this estimator's %r" % (np.asarray(frames[0]).shape, (H, W)))
+        chunks = [(p0, min(p0 + self.chunk_pairs, P)) for p0 in range(0, P, self.chunk_pairs)]
+        stacked = isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
+        bs = int(motion.BBME_BLOCK_SIZE)
+        solve = solve or motion._solve_batch
+
+        def start(lane, chunk):
+            lane.chunk, lane.stage = chunk, 1
             p0, p1 = chunk
             n = p1 - p0 + fd
             if stacked:
                 src = frames[p0:p0 + n]
             else:
+                if lane.host is None:
+                    lane.host = _native.pinned_empty((cap, H, W))
                 for k in range(n):
-                    self.host[k] = frames[p0 + k]
-                src = self.host[:n]
-            self.seq.upload(0, src)              # queued; `src` stays alive (self.host / the caller's array)
-            self.pending = self.seq.gme_begin(fd, bs, procedure, search_window)
+                    lane.host[k] = frames[p0 + k]
+                src = lane.host[:n]
+            lane.seq.upload(0, src)              # queued; `src` stays alive (lane.host / the caller's array)
+            lane.pending = lane.seq.gme_begin(fd, bs, self.procedure, self.search_window)
 
-        def advance(self):
-            """-> True when the chunk is finished (the lane is free again)."""
-            seq, (p0, p1) = self.seq, self.chunk
+        def advance(lane):
+            """Take the lane's result (it has arrived) and queue its next stage -> True when the chunk is finished."""
+            seq, (p0, p1) = lane.seq, lane.chunk
             n = p1 - p0
             seq.wait()
-            if self.stage in (1, 2):
-                level = self.stage
+            if lane.stage in (1, 2):
+                level = lane.stage
                 # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64;
                 # rows behind the chunk's pairs belong to stale frames of an earlier chunk: carried along as zeros
-                p = np.array(self.pending[:n]) if level == 1 else solve(self.pending[:n])
+                p = np.array(lane.pending[:n]) if level == 1 else solve(lane.pending[:n])
                 p[:, 0] = p[:, 0] * 2
                 p[:, 3] = p[:, 3] * 2
                 full = np.zeros((cap - fd, 6))
                 full[:n] = p
-                self.pending = seq.gme_fit(level, full, frac)
-                self.stage += 1
+                lane.pending = seq.gme_fit(level, full, frac)
+                lane.stage += 1
                 return False
-            if self.stage == 3:
-                self.params = solve(self.pending[:n])
+            if lane.stage == 3:
+                lane.params = solve(lane.pending[:n])
                 full = np.zeros((cap - fd, 6))
-                full[:n] = self.params
-                self.pending = seq.compensate(fd, bs, full)
-                self.stage = 4
+                full[:n] = lane.params
+                lane.pending = seq.compensate(fd, bs, full)
+                lane.stage = 4
                 return False
-            params_out[p0:p1] = self.params
-            sse_out[p0:p1] = self.pending[:n]
-            self.ctx.sync()                      # drains the lane and reports a walk that overran its guard
+            params_out[p0:p1] = lane.params
+            sse_out[p0:p1] = lane.pending[:n]
             if compensated is not None:
                 for k in range(n):
                     compensated[p0 + k] = seq.read_compensated(k)
-            self.stage = 0
+            lane.stage = 0
             return True
 
-        def close(self):
-            self.seq.set_split_phase(False)
-            self.seq.close()
-            if self.ctx is not ctx0:
-                self.ctx.close()
-
-    jobs = [Job(ctx0 if j == 0 else _native.Context(ctx0.device)) for j in range(max(1, min(int(streams), len(chunks))))]
-    try:
         todo = list(reversed(chunks))
         busy = []
-        for job in jobs:
+        for lane in self.lanes:
             if todo:
-                job.start(todo.pop())
-                busy.append(job)
+                start(lane, todo.pop())
+                busy.append(lane)
         while busy:
-            for job in list(busy):
-                if job.advance():
-                    if todo:
-                        job.start(todo.pop())
-                    else:
-                        busy.remove(job)
-    finally:
-        for job in jobs:
-            job.close()
-    return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)
+            # serve whichever lane has its result: a lane that waits for its frames must not hold up one whose sums are
+            # back; the lanes furthest along go first, so that their next chunk's upload is queued as early as possible
+            progressed = False
+            for lane in sorted(busy, key=lambda l: -l.stage):
+                if lane.seq.poll():
+                    progressed = True
+                    if advance(lane):
+                        if todo:
+                            start(lane, todo.pop())
+                        else:
+                            busy.remove(lane)
+            if not progressed:
+                max(busy, key=lambda l: l.stage).seq.wait()      # nothing ready: sleep until the most advanced lane is
+        for lane in self.lanes:
+            lane.ctx.sync()                      # drains the lane and reports a walk that overran its guard
+        return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)
+
+
+def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=2, ctx=None, compensated=None, procedure=3,
+                    search_window=2, exact_psnr=True, solve=None):
+    """One-shot StreamEstimator: allocate the lanes, run `frames` through them, release them
+    -> (params float64[P, 6], psnr float64[P]).  Setting the lanes up costs a few milliseconds each; callers with
+    several videos of one size keep a StreamEstimator."""
+    n_frames = len(frames)
+    P = max(0, n_frames - int(frame_distance))
+    if P == 0:
+        return np.zeros((0, 6)), np.zeros(0)
+    H, W = np.asarray(frames[0]).shape
+    chunk_pairs = max(1, min(int(chunk_pairs), P))
+    n_chunks = (P + chunk_pairs - 1) // chunk_pairs
+    with StreamEstimator(H, W, frame_distance, chunk_pairs, max(1, min(int(streams), n_chunks)), ctx, procedure, search_window) as est:
+        return est.run(frames, compensated=compensated, exact_psnr=exact_psnr, solve=solve)

@@ -179,6 +179,8 @@ GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
  * link busy with chunk k + 1 of a video in host memory (results.py:41-50, utils.py:9-31) while chunk k is estimated. */
 GME_API int gme_seq_set_split_phase(gme_seq *seq, int on);
 GME_API int gme_seq_wait(gme_seq *seq);
+/* 1: the result of the last split-phase call has arrived (gme_seq_wait would not block), 0: not yet, < 0: error */
+GME_API int gme_seq_poll(gme_seq *seq);
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, contiguous pair ranges per rank (results.py:41-50 carries no state

@@ -4,6 +4,7 @@ set -e
 cd /root/repo
 L=global-motion-estimation_amd/lib/libgme_hip.so
 cp $L /tmp/keep.so
+trap 'cp /tmp/keep.so $L' EXIT      # the tree's own library comes back whatever happens to a variant
 for r in $(seq 1 ${3:-2}); do
 for v in $1; do
   cp tools/microbench/libgme_$v.so $L
