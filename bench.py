@@ -764,7 +764,7 @@ def measure(opt, ctx, comm, rank, world):
         # the same flow from frames in HOST memory (results.py:41-59 hands the path host arrays): sequence.StreamEstimator
         # uploads chunk k + 1 while chunk k is estimated and compensated; NOT `value`
         import sequence
-        chunk = int(os.environ.get("GME_BENCH_CHUNK", "128"))
+        chunk = int(os.environ.get("GME_BENCH_CHUNK", "512"))
         lanes_e = int(os.environ.get("GME_BENCH_STREAM_LANES", "2"))
         host_frames = native.pinned_empty((B + 1, H, W))
         for lane in shard.lanes:
@@ -786,7 +786,7 @@ def measure(opt, ctx, comm, rank, world):
                                  "host_to_device_GBps": (B + 1) * H * W / t_e / 1e9,
                                  "copy_only": {"GBps": (B + 1) * H * W / t_c / 1e9, "pairs_per_s_if_nothing_else": B / t_c},
                                  "fraction_of_copy_ceiling": t_c / t_e,
-                                 "note": "sequence.StreamEstimator: %d frames from page-locked host memory in chunks of %d pairs over %d lanes "
+                                 "note": "sequence.StreamEstimator: %d frames from page-locked host memory in chunks of at most %d pairs (shrinking towards the end) over %d lanes "
                                          "(split-phase uploads on one shared upload stream, estimate + compensation + PSNR per chunk); "
                                          "parameters and PSNR read back, compensated frames stay on the device" % (B + 1, chunk, lanes_e)}
     if proc == -3:

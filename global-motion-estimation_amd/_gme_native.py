@@ -55,6 +55,7 @@ _SIGNATURES = {
     "gme_seq_create": (_vp, [_vp, _i, _i, _i]),
     "gme_seq_destroy": (None, [_vp]),
     "gme_seq_upload": (_i, [_vp, _i, _i, _c_u8p, _i, ctypes.c_int64]),
+    "gme_seq_set_frames": (_i, [_vp, _i]),
     "gme_seq_synth": (_i, [_vp, ctypes.c_uint64, _i]),
     "gme_seq_read_frame": (_i, [_vp, _i, _i, _c_u8p]),
     "gme_seq_invalidate": (_i, [_vp]),
@@ -291,6 +292,7 @@ class Sequence:
     def __init__(self, ctx, n_frames, height, width):
         self.ctx, self.lib = ctx, ctx.lib
         self.N, self.H, self.W = int(n_frames), int(height), int(width)
+        self.N_cap = self.N                      # frames the device buffers hold; N = frames in use (set_frames)
         self.handle = self.lib.gme_seq_create(ctx.handle, self.N, self.H, self.W)
         if not self.handle:
             raise GmeError("gme_seq_create failed: %s" % self.lib.gme_last_error().decode())
@@ -332,6 +334,12 @@ class Sequence:
         if (H, W) != (self.H, self.W):
             raise ValueError("frame shape %r does not match the sequence %r" % ((H, W), (self.H, self.W)))
         _check(self.lib.gme_seq_upload(self.handle, first, n, _p(frames, _c_u8p), W, H * W), self.lib)
+
+    def set_frames(self, n_frames):
+        """Use only the first `n_frames` frames from now on (1 <= n_frames <= N_cap): every stage call covers the pairs of
+        frames [0, n_frames); the device buffers stay sized for N_cap.  Ends a staged GME run."""
+        _check(self.lib.gme_seq_set_frames(self.handle, int(n_frames)), self.lib)
+        self.N = int(n_frames)
 
     def synth(self, seed, t0=0):
         _check(self.lib.gme_seq_synth(self.handle, seed, t0), self.lib)
@@ -408,7 +416,7 @@ class Sequence:
         -> float64[world, n_max, 6] (each rank's block zero-padded to n_max rows).  In split-phase mode the array
         is filled once wait() returns; `slot` picks one of several page-locked result buffers so that a caller
         can queue the next step while it still reads the previous one."""
-        out = self._buffer("gathered%d" % slot, (int(world), int(n_max), 6), np.float64)
+        out = self._buffer("gathered%d" % slot, (int(world), int(n_max), 6), np.float64, by_frames=False)
         _check(self.lib.gme_seq_mv_summary_gather(self.handle, int(n_max), _p(out, _c_f64p)), self.lib)
         return out
 
@@ -432,20 +440,24 @@ class Sequence:
             _raise(rc, self.lib)
         return rc == 1
 
-    def _buffer(self, name, shape, dtype):
+    def _buffer(self, name, shape, dtype, by_frames=True):
         """Result / argument array of a staged call: ordinary memory, or (split-phase) one page-locked block per
         name and shape kept with the sequence -- the copy engine writes it while the caller is elsewhere."""
         if not getattr(self, "_split", False):
             return np.empty(shape, dtype=dtype)
         pin = self.__dict__.setdefault("_pin", {})
+        shape = tuple(shape)
         a = pin.get(name)
-        if a is None or a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
+        if a is None or a.shape[1:] != shape[1:] or a.shape[0] < shape[0] or a.dtype != np.dtype(dtype):
+            # one block per name, sized for the sequence's full frame count: set_frames() changes the rows in use,
+            # pinning memory anew for every chunk length would cost more than the chunk
+            full = (max(shape[0], self.N_cap) if by_frames else shape[0],) + shape[1:]
             try:
-                a = pinned_empty(shape, dtype) if int(np.prod(shape)) else np.empty(shape, dtype=dtype)
+                a = pinned_empty(full, dtype) if int(np.prod(full)) else np.empty(full, dtype=dtype)
             except MemoryError:                  # no page-locked memory left: the copies still work, they just hold the caller
-                a = np.empty(shape, dtype=dtype)
+                a = np.empty(full, dtype=dtype)
             pin[name] = a
-        return a
+        return a[:shape[0]]
 
     def gme_begin(self, frame_distance, bbme_block_size, procedure=3, search_window=2):
         pairs = self.N - frame_distance

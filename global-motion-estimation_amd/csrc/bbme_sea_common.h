@@ -109,7 +109,7 @@ constexpr int ANCHOR_STRIDE = 68;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Layout {
-    int win, anchor, best, count, a2, s8, work, total;
+    int win, anchor, best, count, a2, prev, s8, work, total;
 };
 
 __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq, int s8_rows)
@@ -121,7 +121,8 @@ __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, in
     l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [2] list lengths of earlier tiles,
                                                        // [3] streak of hostile tiles (persistent_tiles)
     l.a2 = l.count + 4;
-    l.s8 = (l.a2 + nb + 1) & ~1;                       // 8-byte aligned, [s8_rows][xq] u16x4
+    l.prev = l.a2 + nb;                                // [nb] scan index each wave's block of the previous tile ended with (third probe)
+    l.s8 = (l.prev + nb + 1) & ~1;                     // 8-byte aligned, [s8_rows][xq] u16x4
     l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
     l.total = l.work + nb * 64 * R;
     return l;

@@ -128,6 +128,16 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
                 const uint32_t ssd = wave_sum_u32(part);
                 ub_key = u64min_(ub_key, ((unsigned long long)ssd << 13) | (unsigned)idx);
             }
+            // third probe, as in the MAE kernel (bbme_sea.hip): the vector this wave's block of the previous tile ended with
+            const int idxp = (int)(lds[L.prev + wave] & 0x1FFFu);
+            const int cip = idxp / NC, rip = idxp - cip * NC;
+            if (idxp != idx0 && idxp != idx1 && cip >= lo_c && cip <= hi_c && rip >= lo_r && rip <= hi_r) {
+                const int byte = wb.wc * 16 + cip + 4 * aj;
+                const uint32_t* p = win + (16 * wb.wr + rip + arow) * d.pitch_dw + (byte >> 2);
+                const uint32_t v = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)byte & 3u);
+                const uint32_t part = mine2 + __builtin_amdgcn_udot4(v, v, 0u, false) - 2u * __builtin_amdgcn_udot4(v, mine, 0u, false);
+                ub_key = u64min_(ub_key, ((unsigned long long)wave_sum_u32(part) << 13) | (unsigned)idxp);
+            }
         }
         if (lane == 0) best[wave] = ub_key;
         // ---- D
@@ -269,6 +279,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         int32_t* o = d.mf + (((long long)pair * d.nbr + brow) * d.nbc + bcol) * 2;
         o[0] = ci - d.sw;
         o[1] = ri - d.sw;
+        lds[L.prev + wave] = (uint32_t)idx;                // next tile's third probe
     }
     return false;
 }
@@ -313,6 +324,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
         mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
     }
     const typename MseTile<R, LPPT>::Pre pre = MseTile<R, LPPT>::prep(d, lds, L, wave, lane, wb.ok, mine);
+    if (lane == 0) lds[L.prev + wave] = (uint32_t)(d.sw * (2 * d.sw + 16) + d.sw);       // no previous tile: the zero vector
     if (threadIdx.x == 0) lds[L.count] = 0;
     __syncthreads();
     MseTile<R, LPPT>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
@@ -327,7 +339,9 @@ __global__ void __launch_bounds__(1024, (R <= 3 ? 8 : 6)) k_exh_sea16p_mse(SeaDe
 {
     extern __shared__ uint32_t lds[];
     fix_geometry<R, GEO>(d);
-    persistent_tiles<NV, MseTile<R, SEA_MSE_LPP>>(d, lds, layout_of(d, R));
+    const Layout L = layout_of(d, R);
+    if ((threadIdx.x & 63) == 0) lds[L.prev + (threadIdx.x >> 6)] = (uint32_t)(d.sw * (2 * d.sw + 16) + d.sw);    // third probe of the first tile: the zero vector
+    persistent_tiles<NV, MseTile<R, SEA_MSE_LPP>>(d, lds, L);
 }
 
 }  // namespace

@@ -392,7 +392,7 @@ extern "C" gme_seq* gme_seq_create(gme_ctx* ctx, int n_frames, int H, int W)
     if (n_frames < 1 || H < 1 || W < 1) { gme_set_error("gme_seq_create: bad shape"); return nullptr; }
     gme_seq* s = new (std::nothrow) gme_seq();
     if (!s) return nullptr;
-    s->ctx = ctx; s->N = n_frames; s->H = H; s->W = W;
+    s->ctx = ctx; s->N = s->N_cap = n_frames; s->H = H; s->W = W;
     if (plane_alloc(ctx, &s->level[2], n_frames, H, W) != GME_OK) { delete s; return nullptr; }
     return s;
 }
@@ -480,6 +480,24 @@ static void gme_drop_run(gme_seq* s)
     s->gme_pairs = 0;
 }
 
+// The sequence acts as one of `n_frames` frames (1 <= n_frames <= the count it was created with) from now on: every
+// stage call covers the pairs of frames [0, n_frames) only.  Buffers stay sized for the full count, so a caller that
+// streams chunks of different lengths through one sequence (sequence.StreamEstimator) pays for the pairs it has, not for
+// the capacity, and nothing is reallocated.  Ends a staged GME run like new frame data does.
+extern "C" int gme_seq_set_frames(gme_seq* s, int n_frames)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    GME_ENTER(s->ctx);
+    GME_REQUIRE(n_frames >= 1 && n_frames <= s->N_cap, GME_ERR_ARG, "gme_seq_set_frames: %d frames in a sequence created for %d", n_frames, s->N_cap);
+    if (n_frames != s->N) {
+        s->N = n_frames;
+        s->pyramids_valid = false;
+        s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
+        gme_drop_run(s);
+    }
+    return GME_OK;
+}
+
 // One upload lane per device for the split-phase uploads of ALL contexts: host-to-device copies issued from several
 // streams at once share the link badly (two concurrent copy streams moved 22-25 GB/s where one moves 38-54, DESIGN.md
 // section 5; three lanes uploading on their own streams reached 62 % of the copy-alone rate, one shared lane does the
@@ -538,8 +556,8 @@ extern "C" int gme_seq_upload(gme_seq* s, int first, int count, const uint8_t* f
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     GME_ENTER(s->ctx);
-    GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N && row_stride >= s->W, GME_ERR_ARG,
-                "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N);
+    GME_REQUIRE(frames && first >= 0 && count >= 0 && first + count <= s->N_cap && row_stride >= s->W, GME_ERR_ARG,
+                "gme_seq_upload: frames [%d, %d) outside the sequence of %d", first, first + count, s->N_cap);
     gme_ctx* ctx = s->ctx;
     s->pyramids_valid = false;
     s->sqbox_valid[0] = s->sqbox_valid[1] = s->sqbox_valid[2] = false;
@@ -607,7 +625,7 @@ extern "C" int gme_seq_read_frame(gme_seq* s, int level, int index, uint8_t* out
 {
     GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_frame: null pointer");
     GME_ENTER(s->ctx);
-    GME_REQUIRE(level >= 0 && level <= 2 && index >= 0 && index < s->N, GME_ERR_ARG, "gme_seq_read_frame: bad index");
+    GME_REQUIRE(level >= 0 && level <= 2 && index >= 0 && index < s->N_cap, GME_ERR_ARG, "gme_seq_read_frame: bad index");
     GME_REQUIRE(level == 2 || s->pyramids_valid, GME_ERR_STATE, "pyramid levels exist only after gme_seq_gme_begin");
     const Plane& p = s->level[level];
     GME_HIP_TRY(hipMemcpy2DAsync(out, p.W, p.at(index), p.pitch, p.W, p.H, hipMemcpyDeviceToHost, s->ctx->stream));
@@ -637,7 +655,7 @@ static int seq_sqbox(gme_seq* s, int level, int kind)
     int rc = ensure(&s->sqbox[level], &s->sqbox_bytes[level], bytes);
     if (rc) return rc;
     if (!s->sqbox_valid[level] || s->sqbox_kind[level] != kind) {
-        rc = launch_aux_table(s->ctx, kind, p.ptr, p.stride, p.count, p.H, p.W, p.pitch, s->sqbox[level], p.stride);
+        rc = launch_aux_table(s->ctx, kind, p.ptr, p.stride, s->N, p.H, p.W, p.pitch, s->sqbox[level], p.stride);
         if (rc) return rc;
         s->sqbox_valid[level] = true;
         s->sqbox_kind[level] = kind;
@@ -933,7 +951,7 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
     for (int l = 1; l >= 0; --l) {
         const Plane& src = s->level[l + 1];
         if (!s->level[l].ptr) {
-            rc = plane_alloc(ctx, &s->level[l], s->N, (src.H + 1) / 2, (src.W + 1) / 2);
+            rc = plane_alloc(ctx, &s->level[l], s->N_cap, (src.H + 1) / 2, (src.W + 1) / 2);
             if (rc) return rc;
         }
     }
@@ -946,28 +964,31 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
     }
     if (!s->pyramids_valid) {
         for (int l = 1; l >= 0; --l) {
-            rc = launch_pyrdown(ctx, s->level[l + 1], s->level[l]);
+            Plane src = s->level[l + 1], dst = s->level[l];       // views over the frames in use (gme_seq_set_frames)
+            src.count = dst.count = s->N;
+            rc = launch_pyrdown(ctx, src, dst);
             if (rc) return rc;
         }
         s->pyramids_valid = true;
         s->sqbox_valid[0] = s->sqbox_valid[1] = false;
     }
-    if (s->gme_alloc_pairs != (size_t)pairs || s->gme_bs != bbme_bs) {
-        rc = alloc_fit(s->fit[0], pairs, s->level[0].H / 2, s->level[0].W / 2, false);
+    const int cap_pairs = s->N_cap - fd;                   // buffers hold the sequence's full count: gme_seq_set_frames never reallocates
+    if (s->gme_alloc_pairs < (size_t)cap_pairs || s->gme_bs != bbme_bs) {
+        rc = alloc_fit(s->fit[0], cap_pairs, s->level[0].H / 2, s->level[0].W / 2, false);
         if (rc) return rc;
         for (int l = 1; l <= 2; ++l) {
-            rc = alloc_fit(s->fit[l], pairs, s->level[l].H / bbme_bs, s->level[l].W / bbme_bs, true);
+            rc = alloc_fit(s->fit[l], cap_pairs, s->level[l].H / bbme_bs, s->level[l].W / bbme_bs, true);
             if (rc) return rc;
         }
         if (s->params0) hipFree(s->params0);
         if (s->params_in) hipFree(s->params_in);
         s->params0 = nullptr; s->params_in = nullptr;
-        if (hipMalloc((void**)&s->params0, (size_t)pairs * 6 * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&s->params_in, (size_t)pairs * 6 * sizeof(double)) != hipSuccess) {
+        if (hipMalloc((void**)&s->params0, (size_t)cap_pairs * 6 * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&s->params_in, (size_t)cap_pairs * 6 * sizeof(double)) != hipSuccess) {
             gme_set_error("out of device memory (parameters)");
             return GME_ERR_NOMEM;
         }
-        s->gme_alloc_pairs = pairs;
+        s->gme_alloc_pairs = cap_pairs;
     }
     s->gme_fd = fd; s->gme_bs = bbme_bs; s->gme_pairs = pairs;
     s->gme_procedure = procedure; s->gme_sw = sw;
@@ -1103,15 +1124,16 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
     GME_REQUIRE(bs >= 1, GME_ERR_ARG, "block_size %d", bs);
     const int h = s->H / bs, w = s->W / bs;
     GME_REQUIRE(h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
-    if (!s->comp.ptr || s->comp.count != pairs) {
+    if (!s->comp.ptr || s->comp.count < pairs) {
+        const int cap_pairs = s->N_cap - fd > pairs ? s->N_cap - fd : pairs;
         plane_free(&s->comp);
-        rc = plane_alloc(ctx, &s->comp, pairs, s->H, s->W);
+        rc = plane_alloc(ctx, &s->comp, cap_pairs, s->H, s->W);
         if (rc) return rc;
         if (s->sse) hipFree(s->sse);
         if (s->comp_params) hipFree(s->comp_params);
         s->sse = nullptr; s->comp_params = nullptr;
-        if (hipMalloc((void**)&s->sse, (size_t)pairs * sizeof(unsigned long long)) != hipSuccess ||
-            hipMalloc((void**)&s->comp_params, (size_t)pairs * 6 * sizeof(double)) != hipSuccess) {
+        if (hipMalloc((void**)&s->sse, (size_t)cap_pairs * sizeof(unsigned long long)) != hipSuccess ||
+            hipMalloc((void**)&s->comp_params, (size_t)cap_pairs * 6 * sizeof(double)) != hipSuccess) {
             gme_set_error("out of device memory");
             return GME_ERR_NOMEM;
         }

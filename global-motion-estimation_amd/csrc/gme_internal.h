@@ -87,7 +87,8 @@ struct FitLevelBuf {
 
 struct gme_seq {
     gme_ctx* ctx = nullptr;
-    int N = 0, H = 0, W = 0;
+    int N = 0, H = 0, W = 0;      // N: frames in use (gme_seq_set_frames), <= N_cap
+    int N_cap = 0;                // frames the sequence was created for: every buffer is sized for it
     Plane level[3];               // level[2] = full resolution, [1], [0] = pyramid
     bool pyramids_valid = false;
     // generic BBME result

@@ -20,7 +20,7 @@ from utils import draw_motion_field, get_video_frames, write_image
 
 FRAME_DISTANCE = 1          # results.py:11
 STREAMS = 2                 # lanes (context + HIP stream + chunk-sized device sequence) the chunks of a video rotate through
-CHUNK_PAIRS = 128           # pairs per chunk: 129 frames of 720x480 are 45 MB, under a millisecond on the link
+CHUNK_PAIRS = 512           # most pairs per chunk (a lane's device sequence holds that many + fd frames); StreamEstimator.schedule shrinks the last ones
 
 
 def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progress=False, model="affine"):

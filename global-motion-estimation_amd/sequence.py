@@ -491,7 +491,7 @@ class ShardedSequence:
 class StreamEstimator:
     """results.py:41-59,109 for videos that still live in HOST memory: ``run(frames)`` -> (params float64[P, 6], psnr float64[P]).
 
-    A video is cut into chunks of ``chunk_pairs`` pairs (plus the ``fd`` halo frames); ``streams`` lanes -- each its own
+    A video is cut into chunks of at most ``chunk_pairs`` pairs (plus the ``fd`` halo frames; see schedule()); ``streams`` lanes -- each its own
     context, HIP stream and (chunk_pairs + fd)-frame device sequence, allocated once here and reused by every run() --
     take the chunks in turn.  Everything a lane does is split-phase (gme_seq_set_split_phase): the upload of its chunk
     (on the device's shared upload stream), pyramids + dense field, level fits, compensation are queued and ONE host
@@ -506,9 +506,11 @@ class StreamEstimator:
     reference's two 3x3 systems), roadmap.solve_model for the other motion models.
     Results equal the resident path bit for bit (tests/test_gpu_round3.py)."""
 
-    def __init__(self, height, width, frame_distance=1, chunk_pairs=128, streams=2, ctx=None, procedure=3, search_window=2):
+    def __init__(self, height, width, frame_distance=1, chunk_pairs=512, streams=2, ctx=None, procedure=3, search_window=2,
+                 min_chunk=64):
         self.H, self.W, self.fd = int(height), int(width), int(frame_distance)
         self.chunk_pairs = max(1, int(chunk_pairs))
+        self.min_chunk = max(1, min(int(min_chunk), self.chunk_pairs))
         self.cap = self.chunk_pairs + self.fd                    # frames a lane holds
         self.procedure, self.search_window = procedure, search_window
         self.ctx = ctx or _native.default_context()
@@ -547,6 +549,20 @@ class StreamEstimator:
     def __exit__(self, *exc):
         self.close(check=exc[0] is None)
 
+    def schedule(self, n_pairs):
+        """Chunks [(first pair, end pair)] of a video of `n_pairs` pairs: as large as a lane holds while much is left (each
+        chunk costs the host four round trips whatever its size), shrinking towards the end -- a quarter of what is left per
+        lane, at least `min_chunk` -- because the estimate of the LAST chunk is the one stretch no upload hides (traced:
+        with equal chunks of 1024 pairs the link idles 2.5 of 15.9 ms behind the last copy, with equal chunks of 128 the
+        host's round trips leave gaps between the copies)."""
+        out, p0 = [], 0
+        while p0 < n_pairs:
+            left = n_pairs - p0
+            c = min(self.chunk_pairs, max(self.min_chunk, -(-left // (2 * max(1, len(self.lanes))))), left)
+            out.append((p0, p0 + c))
+            p0 += c
+        return out
+
     def run(self, frames, compensated=None, exact_psnr=True, solve=None):
         fd, H, W, cap = self.fd, self.H, self.W, self.cap
         P = max(0, len(frames) - fd)
@@ -555,7 +571,7 @@ class StreamEstimator:
             return params_out, np.zeros(0)
         if tuple(np.asarray(frames[0]).shape) != (H, W):
             raise ValueError("frames of %r do not fit this estimator's %r" % (np.asarray(frames[0]).shape, (H, W)))
-        chunks = [(p0, min(p0 + self.chunk_pairs, P)) for p0 in range(0, P, self.chunk_pairs)]
+        chunks = self.schedule(P)
         stacked = isinstance(frames, np.ndarray) and frames.ndim == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
         frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
         bs = int(motion.BBME_BLOCK_SIZE)
@@ -573,6 +589,7 @@ class StreamEstimator:
                 for k in range(n):
                     lane.host[k] = frames[p0 + k]
                 src = lane.host[:n]
+            lane.seq.set_frames(n)               # the stages cover this chunk's pairs only; buffers stay sized for `cap`
             lane.seq.upload(0, src)              # queued; `src` stays alive (lane.host / the caller's array)
             lane.pending = lane.seq.gme_begin(fd, bs, self.procedure, self.search_window)
 
@@ -583,21 +600,16 @@ class StreamEstimator:
             seq.wait()
             if lane.stage in (1, 2):
                 level = lane.stage
-                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64;
-                # rows behind the chunk's pairs belong to stale frames of an earlier chunk: carried along as zeros
+                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
                 p = np.array(lane.pending[:n]) if level == 1 else solve(lane.pending[:n])
                 p[:, 0] = p[:, 0] * 2
                 p[:, 3] = p[:, 3] * 2
-                full = np.zeros((cap - fd, 6))
-                full[:n] = p
-                lane.pending = seq.gme_fit(level, full, frac)
+                lane.pending = seq.gme_fit(level, p, frac)
                 lane.stage += 1
                 return False
             if lane.stage == 3:
                 lane.params = solve(lane.pending[:n])
-                full = np.zeros((cap - fd, 6))
-                full[:n] = lane.params
-                lane.pending = seq.compensate(fd, bs, full)
+                lane.pending = seq.compensate(fd, bs, lane.params)
                 lane.stage = 4
                 return False
             params_out[p0:p1] = lane.params
@@ -633,8 +645,8 @@ class StreamEstimator:
         return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)
 
 
-def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=2, ctx=None, compensated=None, procedure=3,
-                    search_window=2, exact_psnr=True, solve=None):
+def estimate_stream(frames, frame_distance=1, chunk_pairs=512, streams=2, ctx=None, compensated=None, procedure=3,
+                    search_window=2, exact_psnr=True, solve=None, min_chunk=64):
     """One-shot StreamEstimator: allocate the lanes, run `frames` through them, release them
     -> (params float64[P, 6], psnr float64[P]).  Setting the lanes up costs a few milliseconds each; callers with
     several videos of one size keep a StreamEstimator."""
@@ -645,5 +657,6 @@ def estimate_stream(frames, frame_distance=1, chunk_pairs=128, streams=2, ctx=No
     H, W = np.asarray(frames[0]).shape
     chunk_pairs = max(1, min(int(chunk_pairs), P))
     n_chunks = (P + chunk_pairs - 1) // chunk_pairs
-    with StreamEstimator(H, W, frame_distance, chunk_pairs, max(1, min(int(streams), n_chunks)), ctx, procedure, search_window) as est:
+    with StreamEstimator(H, W, frame_distance, chunk_pairs, max(1, min(int(streams), n_chunks)), ctx, procedure, search_window,
+                         min_chunk=min_chunk) as est:
         return est.run(frames, compensated=compensated, exact_psnr=exact_psnr, solve=solve)

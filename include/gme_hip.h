@@ -114,6 +114,10 @@ GME_API gme_seq *gme_seq_create(gme_ctx *ctx, int n_frames, int H, int W);
 GME_API void gme_seq_destroy(gme_seq *seq);
 GME_API int gme_seq_upload(gme_seq *seq, int first, int count, const uint8_t *frames, int row_stride,
                    int64_t frame_stride);
+/* Use only the first n_frames frames (1 <= n_frames <= the count given to gme_seq_create) from now on: every stage call covers
+ * the pairs of frames [0, n_frames) -- results.py:41-48 over a shorter list -- while the buffers stay sized for the full count.
+ * How one sequence serves chunks of different lengths of a longer video (sequence.StreamEstimator).  Ends a staged GME run. */
+GME_API int gme_seq_set_frames(gme_seq *seq, int n_frames);
 /* deterministic synthetic frames t0 .. t0+N-1 generated on the device */
 GME_API int gme_seq_synth(gme_seq *seq, uint64_t seed, int t0);
 /* mark the pyramid levels stale (upload and synth do so themselves) */

@@ -112,6 +112,33 @@ def test_split_phase_upload_and_pageable_result_buffers(native, monkeypatch):
     seq.close()
 
 
+def test_set_frames_limits_the_stages(native):
+    """gme_seq_set_frames: a sequence created for 12 frames acts as one of 5, then 9, then 12 -- block matching, the staged
+    estimate and the compensation cover exactly the pairs of the frames in use and equal a fresh sequence of that length."""
+    import motion
+    import synth
+    ctx = native.default_context()
+    frames = synth.sequence(21, 0, 12, 96, 160)
+    big = native.Sequence(ctx, 12, 96, 160)
+    big.upload(0, frames)
+    for n in (5, 9, 12, 2):
+        big.set_frames(n)
+        big.upload(0, frames[:n])
+        ref = native.Sequence.from_frames(ctx, frames[:n])
+        for seq in (big, ref):
+            seq.bbme(1, 16, 16, 0, 1)
+        assert big.read_mv().shape[0] == n - 1 and np.array_equal(big.read_mv(), ref.read_mv()), n
+        p_big, p_ref = motion.estimate_sequence(big, 1), motion.estimate_sequence(ref, 1)
+        assert p_big.shape == (n - 1, 6) and np.array_equal(p_big, p_ref), n
+        assert np.array_equal(big.compensate(1, 16, p_big), ref.compensate(1, 16, p_ref)), n
+        assert np.array_equal(big.read_compensated(n - 2), ref.read_compensated(n - 2)), n
+        ref.close()
+    for bad in (0, 13):
+        with pytest.raises(IndexError):
+            big.set_frames(bad)
+    big.close()
+
+
 def test_cli_results_model_and_suggest(golden, native, tmp_path, monkeypatch, capsys):
     """gme_cli results --model / --suggest (recap_future_updates.md:9-14, extensions): the affine default writes the
     reference's psnr_records (g7 flow); a non-affine model and the suggested constants run end to end and report what they chose."""

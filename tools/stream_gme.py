@@ -24,7 +24,7 @@ seq.upload(0, frames)
 t_copy = time.perf_counter() - t0
 seq.close()
 print("copy alone: %.2f ms = %.1f GB/s -> %.0f pairs/s if nothing else" % (1e3 * t_copy, n * H * W / t_copy / 1e9, (n - 1) / t_copy))
-for chunk, lanes in ((128, 2), (256, 2), (256, 3), (512, 2), (512, 3), (1024, 2)):
+for chunk, lanes in ((512, 2), (512, 3), (1024, 2), (256, 2), (256, 3), (128, 3)):
     with sequence.StreamEstimator(H, W, 1, chunk, lanes) as est:
         est.run(frames, exact_psnr=False)      # first touch
         best = 1e9
