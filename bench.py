@@ -671,8 +671,10 @@ def measure(opt, ctx, comm, rank, world):
             reason = "profile is of the default single-GPU command"
         if reason is None and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             out["roofline"]["traffic"] = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            out["roofline"]["traffic_source"] = ("committed profile profiles/%s, kernel %s: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
-                                                 "x2 = the guide's gfx950 FETCH_SIZE correction" % (pname, vals["_kernel"]))
+            out["roofline"]["traffic_source"] = ("committed profile profiles/%s, kernel %s: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch "
+                                                 "(mean over that kernel's launches of this command%s), x2 = the guide's gfx950 FETCH_SIZE "
+                                                 "correction" % (pname, vals["_kernel"], "; [grid=N]: the launches of that grid size only, "
+                                                 "i.e. the level-2 search of one pair range" if "[grid=" in vals["_kernel"] else ""))
         else:
             out["roofline"]["traffic_source"] = "null: " + (reason or "no FETCH_SIZE/WRITE_SIZE in the committed profile")
         if reason is None and all(k in vals for k in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU",

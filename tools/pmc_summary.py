@@ -24,12 +24,20 @@ except Exception as e:      # noqa: BLE001
     print("# kernel_source_sha: unknown (%r)" % (e,))
 for path in sorted(glob.glob(root + "/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
+    bygrid = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for r in csv.DictReader(open(path)):
         if needle in r["Kernel_Name"]:
             agg[(kname(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            bygrid[(kname(r["Kernel_Name"]), r["Counter_Name"])][r["Grid_Size"]].append(float(r["Counter_Value"]))
             meta[kname(r["Kernel_Name"])] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
     for (k, c), v in sorted(agg.items()):
         print("%-50s %-24s dispatches=%-3d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+    # a kernel launched with several grid sizes in one step (the level-1 and level-2 searches of a GME step): one more line
+    # per grid size, so that a launch can be rated on its own ("name[grid=N]")
+    for (k, c), by in sorted(bygrid.items()):
+        if len(by) > 1:
+            for g, v in sorted(by.items(), key=lambda x: int(x[0])):
+                print("%-50s %-24s dispatches=%-3d mean=%.6g" % ("%s[grid=%s]" % (k, g), c, len(v), sum(v) / len(v)))
     for k, m in meta.items():
         print("#   %s grid=%s wg=%s lds=%s vgpr=%s sgpr=%s" % ((k,) + m))
