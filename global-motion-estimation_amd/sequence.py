@@ -59,7 +59,7 @@ def _process_start_time():
 
 
 _IMPORT_TIME = time.time()
-_STALE_SLACK_S = 5.0
+_STALE_SLACK_S = 60.0        # ranks of one launch may start (and publish) this much apart; an earlier launch's files are older
 
 
 def _rendezvous_base():
@@ -84,7 +84,7 @@ class Rendezvous:
     """File-based exchange of small blobs between the ranks of one launch on one node: publish(key, blob) writes
     <base>.<key>.<rank> atomically (0600, O_EXCL | O_NOFOLLOW); collect(key) returns every rank's blob once all are
     there.  A file is accepted only if it is a regular file of this user and not older than this process (minus a few
-    seconds of start-up skew): what an earlier launch with the same port and parent left behind is never read."""
+    minute of start-up skew): what an earlier launch with the same port and parent left behind is never read."""
 
     def __init__(self, rank, world, timeout_s=180.0, base=None):
         self.rank, self.world, self.timeout_s = int(rank), int(world), float(timeout_s)

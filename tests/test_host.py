@@ -339,6 +339,23 @@ def test_comm_init_is_decided_by_all_ranks(tmp_path, scenario):
         assert all("comm=False" in outs[r] for r in range(3)), outs              # ranks 0 and 2 gave theirs back
 
 
+def test_stream_schedule_covers_every_pair_once():
+    """StreamEstimator.schedule: chunks no larger than a lane holds, shrinking towards the end (the last chunk's estimate is
+    the stretch no upload hides), never below min_chunk except for the remainder, every pair exactly once."""
+    import sequence
+    est = sequence.StreamEstimator.__new__(sequence.StreamEstimator)
+    for cap, mn, lanes, P in ((512, 64, 2, 2048), (512, 64, 3, 2048), (128, 128, 2, 1000), (7, 7, 3, 50), (1000, 64, 2, 50), (16, 4, 1, 1), (64, 64, 2, 0)):
+        est.chunk_pairs, est.min_chunk, est.lanes = cap, min(mn, cap), [None] * lanes
+        ch = est.schedule(P)
+        assert (not ch and P == 0) or (ch[0][0] == 0 and ch[-1][1] == P), (cap, mn, lanes, P, ch)
+        assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        sizes = [b - a for a, b in ch]
+        assert all(0 < n <= cap for n in sizes) and sizes == sorted(sizes[:-1], reverse=True) + sizes[-1:], sizes
+        assert all(n >= min(mn, cap) for n in sizes[:-1]), sizes
+    est.chunk_pairs, est.min_chunk, est.lanes = 512, 64, [None, None]
+    assert [b - a for a, b in est.schedule(2048)] == [512, 384, 288, 216, 162, 122, 91, 69, 64, 64, 64, 12]
+
+
 def test_bench_helpers():
     """bench.py's sampling (first and last pair always in), content stacks and profile identity."""
     sys.path.insert(0, REPO)
