@@ -75,6 +75,7 @@ _SIGNATURES = {
     "gme_comm_allreduce_max": (_i, [_vp, _c_f64p, _i]),
     "gme_seq_gme_begin": (_i, [_vp, _i, _i, _i, _i, _c_f32p]),
     "gme_seq_gme_fit": (_i, [_vp, _i, _c_f64p, ctypes.c_double, _c_f64p]),
+    "gme_seq_gme_begin_fit": (_i, [_vp, _i, _i, _i, _i, ctypes.c_double, _c_f32p, _c_f64p]),
     "gme_seq_gme_read_stage": (_i, [_vp, _i, _i, _c_i32p, _c_i16p, _c_u8p, _c_i64p]),
     "gme_seq_compensate": (_i, [_vp, _i, _i, _c_f64p, _c_i64p]),
     "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
@@ -467,6 +468,18 @@ class Sequence:
                                           _p(p0, _c_f32p)), self.lib)
         self._gme = (frame_distance, bbme_block_size, pairs)
         return p0
+
+    def gme_begin_fit(self, frame_distance, bbme_block_size, outlier_fraction, procedure=3, search_window=2):
+        """gme_begin + projection of the first parameters + gme_fit(level 1) without the trip to the host in between
+        -> (first parameters float32[P, 6], level-1 sums float64[P, 15]); the level-2 search is queued behind."""
+        pairs = self.N - frame_distance
+        bbme_block_size = _block_size(bbme_block_size)
+        p0 = self._buffer("p0", (max(pairs, 0), 6), np.float32)
+        sums = self._buffer("sums1", (max(pairs, 0), 15), np.float64)
+        _check(self.lib.gme_seq_gme_begin_fit(self.handle, frame_distance, bbme_block_size, procedure, search_window,
+                                              float(outlier_fraction), _p(p0, _c_f32p), _p(sums, _c_f64p)), self.lib)
+        self._gme = (frame_distance, bbme_block_size, pairs)
+        return p0, sums
 
     def gme_fit(self, level, params_in, outlier_fraction):
         """-> sums float64[P, 15] = F (9) | Sx (3) | Sy (3).  level -1 fits the field of the

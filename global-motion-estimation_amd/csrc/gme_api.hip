@@ -124,6 +124,44 @@ static int ctx_finish(gme_ctx* ctx)
     return GME_OK;
 }
 
+// Small results and arguments of the split-phase calls (parameters, sums, squared errors: a few dozen KB) do not go
+// through hipMemcpyAsync when the caller's buffer is page-locked: the copy engines serve copies in order, and a 60 KB result
+// queued behind another context's 177 MB upload arrived 3.4 ms late -- every stage of a streamed estimate waited for
+// whatever chunk was crossing the link (round 3 timeline).  Page-locked memory (gme_host_alloc /
+// hipHostMalloc) is mapped into the device's address space, so a kernel on the context's own stream moves the words
+// itself.  Ordinary memory falls back to hipMemcpyAsync.
+__global__ void __launch_bounds__(256) k_copy_words(const uint32_t* src, uint32_t* dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+static bool mapped_host_view(const void* host, void** dev)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return false; }      // ordinary memory: not an error
+    if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return false;
+    *dev = at.devicePointer;
+    return true;
+}
+
+// dst <- src of `bytes` (a multiple of 4) on the context's stream; exactly one of the two is host memory
+static int copy_small(gme_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool prefer_kernel)
+{
+    if (bytes == 0) return GME_OK;
+    void* view = nullptr;
+    if (prefer_kernel && bytes % 4 == 0 && bytes <= ((size_t)16 << 20) && mapped_host_view(kind == hipMemcpyDeviceToHost ? dst : src, &view)) {
+        const uint32_t* s4 = (const uint32_t*)(kind == hipMemcpyDeviceToHost ? src : view);
+        uint32_t* d4 = (uint32_t*)(kind == hipMemcpyDeviceToHost ? view : dst);
+        const size_t n = bytes / 4;
+        const unsigned grid = (unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+        hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, ctx->stream, s4, d4, n);
+        GME_HIP_TRY(hipGetLastError());
+        return GME_OK;
+    }
+    GME_HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    return GME_OK;
+}
+
 extern "C" int gme_sync(gme_ctx* ctx)
 {
     GME_ENTER(ctx);
@@ -793,15 +831,17 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
         back_count = 0;
         return ok;
     };
-    for (int c = 0; c < nchunks; ++c) {
+#define LTRY(expr) do { if ((expr) != hipSuccess) return false; } while (0)
+    // upload of chunk c on the copy stream + the event behind it
+    auto upload_chunk = [&](int c) -> bool {
         const int f0 = c * chunk_frames, f1 = f0 + chunk_frames < count ? f0 + chunk_frames : count;
-        STREAM_TRY(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
-        STREAM_TRY(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
+        LTRY(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
+        LTRY(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
         // upload of chunk c on the copy stream: it runs while the compute stream still searches chunk c - 1
         if (tight && host_mapped) {
             // page-locked frames are mapped into the device's address space: the repack kernel reads them across the
             // link itself (thousands of loads in flight instead of one DMA queue) and writes the pitched planes
-            if (launch_repack(ctx, ctx->copy_stream, dev_view + (int64_t)f0 * frame_stride, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) { STREAM_TRY(hipErrorUnknown); }
+            if (launch_repack(ctx, ctx->copy_stream, dev_view + (int64_t)f0 * frame_stride, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) return false;
         } else if (tight) {
             // one linear copy (link speed), then spread into the pitched planes on the same stream: the next chunk's
             // copy into the staging buffer is ordered behind this repack
@@ -810,24 +850,34 @@ extern "C" int gme_seq_bbme_streamed(gme_seq* s, const uint8_t* frames, int row_
             if (two_engines && bytes >= (1u << 20)) {
                 // second half through a second stream: two copy engines share the link (one alone moved ~40 GB/s)
                 head = (bytes / 2) & ~(size_t)4095;
-                if (c > 0) STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream2, up[c - 1], 0));      // staging buffer free again
-                STREAM_TRY(hipMemcpyAsync(ctx->stage + head, frames + (int64_t)f0 * frame_stride + head, bytes - head,
+                if (c > 0) LTRY(hipStreamWaitEvent(ctx->copy_stream2, up[c - 1], 0));      // staging buffer free again
+                LTRY(hipMemcpyAsync(ctx->stage + head, frames + (int64_t)f0 * frame_stride + head, bytes - head,
                                           hipMemcpyHostToDevice, ctx->copy_stream2));
-                STREAM_TRY(hipEventRecord(done[c], ctx->copy_stream2));                          // done[c] is re-recorded behind the kernel below
+                LTRY(hipEventRecord(done[c], ctx->copy_stream2));                          // done[c] is re-recorded behind the kernel below
             }
-            STREAM_TRY(hipMemcpyAsync(ctx->stage, frames + (int64_t)f0 * frame_stride, head, hipMemcpyHostToDevice, ctx->copy_stream));
-            if (head != bytes) STREAM_TRY(hipStreamWaitEvent(ctx->copy_stream, done[c], 0));
-            if (launch_repack(ctx, ctx->copy_stream, ctx->stage, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) { STREAM_TRY(hipErrorUnknown); }
+            LTRY(hipMemcpyAsync(ctx->stage, frames + (int64_t)f0 * frame_stride, head, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (head != bytes) LTRY(hipStreamWaitEvent(ctx->copy_stream, done[c], 0));
+            if (launch_repack(ctx, ctx->copy_stream, ctx->stage, f1 - f0, s->H, s->W, p.at(f0), p.pitch, p.stride) != GME_OK) return false;
         } else if (p.stride == (int64_t)p.pitch * s->H && frame_stride == (int64_t)row_stride * s->H) {
-            STREAM_TRY(hipMemcpy2DAsync(p.at(f0), p.pitch, frames + (int64_t)f0 * frame_stride, row_stride, s->W,
+            LTRY(hipMemcpy2DAsync(p.at(f0), p.pitch, frames + (int64_t)f0 * frame_stride, row_stride, s->W,
                                         (size_t)s->H * (f1 - f0), hipMemcpyHostToDevice, ctx->copy_stream));
         } else {
             for (int i = f0; i < f1; ++i)
-                STREAM_TRY(hipMemcpy2DAsync(p.at(i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
+                LTRY(hipMemcpy2DAsync(p.at(i), p.pitch, frames + (int64_t)i * frame_stride, row_stride, s->W, s->H,
                                             hipMemcpyHostToDevice, ctx->copy_stream));
         }
-        STREAM_TRY(hipEventRecord(up[c], ctx->copy_stream));
-        // read-back of the previous chunk's fields only now, behind this chunk's upload in program order: a copy
+        LTRY(hipEventRecord(up[c], ctx->copy_stream));
+        return true;
+    };
+#undef LTRY
+    if (!upload_chunk(0)) { STREAM_TRY(hipErrorUnknown); }
+    for (int c = 0; c < nchunks; ++c) {
+        const int f1 = (c + 1) * chunk_frames < count ? (c + 1) * chunk_frames : count;
+        // The NEXT chunk's upload is queued before this chunk's search is launched: a kernel launch behind a cross-stream
+        // wait on a copy holds the calling thread until that copy is done, and with the upload queued only afterwards the
+        // link idled for the host's latency between chunks (94 % of the copy-alone rate; round 3).
+        if (c + 1 < nchunks && !upload_chunk(c + 1)) { STREAM_TRY(hipErrorUnknown); }
+        // read-back of the previous chunk's fields only now, behind the next chunk's upload in program order: a copy
         // into pageable memory may hold the calling thread until that chunk's kernel is done, and the upload
         // queued above keeps the link busy meanwhile
         if (!read_back()) { STREAM_TRY(hipErrorUnknown); }
@@ -938,11 +988,10 @@ static int gme_flush_bbme(gme_seq* s, int level)
     return GME_OK;
 }
 
-extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, float* params0_out)
+// pyramids, buffers, dense field and first parameters (motion.py:123-128,160-188) of a staged run; the context is locked
+static int gme_begin_common(gme_seq* s, int fd, int bbme_bs, int procedure, int sw)
 {
-    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     gme_ctx* ctx = s->ctx;
-    GME_ENTER(ctx);
     int rc = GME_OK;
     GME_REQUIRE(fd >= 1 && fd < s->N, GME_ERR_ARG, "frame_distance %d needs at least %d frames", fd, fd + 1);
     GME_REQUIRE(bbme_bs >= 1, GME_ERR_ARG, "block_size %d", bbme_bs);
@@ -1001,17 +1050,49 @@ extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure,
     rc = gme_level_bbme(s, 0);
     if (rc) return rc;
     GME_REQUIRE(s->fit[0].h > 0 && s->fit[0].w > 0, GME_ERR_GEOMETRY, "frames too small for a dense field");
-    rc = launch_first_params(ctx, s->fit[0].gt, pairs, s->fit[0].h * s->fit[0].w, s->params0);
+    return launch_first_params(ctx, s->fit[0].gt, pairs, s->fit[0].h * s->fit[0].w, s->params0);
+}
+
+extern "C" int gme_seq_gme_begin(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, float* params0_out)
+{
+    GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
+    gme_ctx* ctx = s->ctx;
+    GME_ENTER(ctx);
+    int rc = gme_begin_common(s, fd, bbme_bs, procedure, sw);
     if (rc) return rc;
     if (params0_out) {
-        GME_HIP_TRY(hipMemcpyAsync(params0_out, s->params0, (size_t)pairs * 6 * sizeof(float), hipMemcpyDeviceToHost,
-                                   ctx->stream));
+        rc = copy_small(ctx, params0_out, s->params0, (size_t)s->gme_pairs * 6 * sizeof(float), hipMemcpyDeviceToHost, s->split_phase);
+        if (rc) return rc;
         if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
         else rc = ctx_finish(ctx);
         if (rc) return rc;
         return gme_level_bbme(s, 1);                       // runs while the caller projects the parameters
     }
     return gme_flush_bbme(s, 2);
+}
+
+static int fit_level_launch(gme_seq* s, int level, const double* dparams, double outlier_fraction, double* sums_out);
+
+// gme_seq_gme_begin + the projection of the first parameters (motion.py:191-207 on the float32 vector: two exact doublings)
+// + gme_seq_gme_fit(level 1) without the trip to the host in between: the first parameters never leave the device on the
+// way to the level-1 fit, so a staged run has three dependent host round trips instead of four.  params0_out may be NULL.
+extern "C" int gme_seq_gme_begin_fit(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, double outlier_fraction,
+                                     float* params0_out, double* sums1_out)
+{
+    GME_REQUIRE(s != nullptr && sums1_out != nullptr, GME_ERR_ARG, "gme_seq_gme_begin_fit: null pointer");
+    gme_ctx* ctx = s->ctx;
+    GME_ENTER(ctx);
+    int rc = gme_begin_common(s, fd, bbme_bs, procedure, sw);
+    if (rc) return rc;
+    rc = launch_project_first(ctx, s->params0, s->gme_pairs, s->params_in);
+    if (rc) return rc;
+    if (params0_out)
+        { rc = copy_small(ctx, params0_out, s->params0, (size_t)s->gme_pairs * 6 * sizeof(float), hipMemcpyDeviceToHost, s->split_phase); if (rc) return rc; }
+    rc = gme_level_bbme(s, 1);
+    if (rc) return rc;
+    rc = fit_level_launch(s, 1, s->params_in, outlier_fraction, sums1_out);
+    if (rc) return rc;
+    return gme_level_bbme(s, 2);                           // searched while the caller solves level 1
 }
 
 static int ensure_fit_mv(gme_seq* s)
@@ -1069,21 +1150,47 @@ extern "C" int gme_seq_gme_fit(gme_seq* s, int level, const double* params_in, d
         f = &s->fit[level]; pairs = s->gme_pairs; level_H = s->level[level].H; level_W = s->level[level].W;
         dparams = s->params_in;
     }
-    const int n = f->h * f->w;
+    if (level == -1) {
+        const int n = f->h * f->w;
+        GME_REQUIRE(n > 0, GME_ERR_GEOMETRY, "level %d holds no block (motion.py:243 would index an empty list)", level);
+        // int(0.3 * len), motion.py:242; a negative fraction selects the unmasked fit (motion.py:33-88)
+        const int drop = outlier_fraction < 0 ? -1 : (int)(outlier_fraction * (double)n);
+        GME_REQUIRE(drop <= n, GME_ERR_ARG, "outlier fraction %g out of range", outlier_fraction);
+        GME_HIP_TRY(hipMemcpyAsync(dparams, params_in, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, level_H, level_W, f->model, f->mask, f->diff,
+                              f->thr, f->sums, f->list);
+        if (rc) return rc;
+        GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
+        else rc = ctx_finish(ctx);
+        return rc;
+    }
+    rc = copy_small(ctx, dparams, params_in, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, s->split_phase);
+    if (rc) return rc;
+    rc = fit_level_launch(s, level, dparams, outlier_fraction, sums_out);
+    if (rc) return rc;
+    if (level == 1) return gme_level_bbme(s, 2);           // searched while the caller solves level 1
+    return GME_OK;
+}
+
+// model field, mask and sums of GME level 1 or 2 from parameters already on the device; result copy + event / wait
+static int fit_level_launch(gme_seq* s, int level, const double* dparams, double outlier_fraction, double* sums_out)
+{
+    gme_ctx* ctx = s->ctx;
+    const FitLevelBuf* f = &s->fit[level];
+    const int pairs = s->gme_pairs, n = f->h * f->w;
     GME_REQUIRE(n > 0, GME_ERR_GEOMETRY, "level %d holds no block (motion.py:243 would index an empty list)", level);
     // int(0.3 * len), motion.py:242; a negative fraction selects the unmasked fit (motion.py:33-88)
     const int drop = outlier_fraction < 0 ? -1 : (int)(outlier_fraction * (double)n);
     GME_REQUIRE(drop <= n, GME_ERR_ARG, "outlier fraction %g out of range", outlier_fraction);
-    GME_HIP_TRY(hipMemcpyAsync(dparams, params_in, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, level_H, level_W, f->model, f->mask, f->diff,
-                          f->thr, f->sums, f->list);
+    int rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, s->level[level].H, s->level[level].W, f->model, f->mask,
+                              f->diff, f->thr, f->sums, f->list);
     if (rc) return rc;
-    GME_HIP_TRY(hipMemcpyAsync(sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    rc = copy_small(ctx, sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, s->split_phase);
+    if (rc) return rc;
     if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
     else rc = ctx_finish(ctx);
-    if (rc) return rc;
-    if (level == 1) return gme_level_bbme(s, 2);           // searched while the caller solves level 1
-    return GME_OK;
+    return rc;
 }
 
 extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* gt, int16_t* model, uint8_t* mask,
@@ -1138,13 +1245,15 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
             return GME_ERR_NOMEM;
         }
     }
-    GME_HIP_TRY(hipMemcpyAsync(s->comp_params, params, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = copy_small(ctx, s->comp_params, params, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, s->split_phase);
+    if (rc) return rc;
     const Plane& p = s->level[2];
     rc = launch_compensate(ctx, p.at(0), p.stride, pairs, s->H, s->W, p.pitch, nullptr, s->comp_params, h, w, s->comp.ptr,
                            s->comp.stride, s->comp.pitch, p.at(fd), p.stride, s->sse);
     if (rc) return rc;
     if (sse_out) {
-        GME_HIP_TRY(hipMemcpyAsync(sse_out, s->sse, (size_t)pairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        rc = copy_small(ctx, sse_out, s->sse, (size_t)pairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->split_phase);
+        if (rc) return rc;
         if (s->split_phase) { GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream)); return GME_OK; }
         return ctx_finish(ctx);
     }

@@ -176,6 +176,7 @@ int launch_repack(gme_ctx* ctx, hipStream_t stream, const uint8_t* src, int coun
                   long long dst_stride);
 int launch_pyrdown(gme_ctx* ctx, const Plane& src, const Plane& dst);
 int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blocks, float* params0);
+int launch_project_first(gme_ctx* ctx, const float* params0, int pairs, double* params_in);
 int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, const double* params,
                      int drop_count, int level_H, int level_W, int16_t* model, uint8_t* mask,
                      int32_t* diff, int32_t* thr, double* sums, void* list);

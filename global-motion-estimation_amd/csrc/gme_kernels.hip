@@ -266,6 +266,18 @@ __global__ void __launch_bounds__(256) k_first_params(const int32_t* dense, int 
     }
 }
 
+// motion.parameter_projection (motion.py:191-207) of the float32 first parameters on the device: p[0] and p[3] doubled in
+// float32 (exact), the vector widened to the float64 the level-1 fit reads -- what the host does between
+// gme_seq_gme_begin and gme_seq_gme_fit(1), without the trip (gme_seq_gme_begin_fit)
+__global__ void __launch_bounds__(256) k_project_first(const float* params0, int n, double* params_in)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = i % 6;
+    const float v = params0[i];
+    params_in[i] = (double)((k == 0 || k == 3) ? v * 2.0f : v);
+}
+
 // ---------------------------------------------------------------------------
 // Per-pair summary row of a motion field -- what a sharded block-matching run exchanges instead of the
 // fields themselves (gme_seq_mv_summary[_gather]): float64[6] =
@@ -798,6 +810,14 @@ int launch_first_params(gme_ctx* ctx, const int32_t* dense, int pairs, int n_blo
 {
     if (pairs == 0) return GME_OK;
     hipLaunchKernelGGL(k_first_params, dim3(pairs), dim3(256), 0, ctx->stream, dense, n_blocks, params0);
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_project_first(gme_ctx* ctx, const float* params0, int pairs, double* params_in)
+{
+    if (pairs == 0) return GME_OK;
+    hipLaunchKernelGGL(k_project_first, dim3((pairs * 6 + 255) / 256), dim3(256), 0, ctx->stream, params0, pairs * 6, params_in);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }

@@ -128,12 +128,13 @@ def estimate_sequence(seq, frame_distance=1, procedure=3, search_window=2):
         raise RuntimeError("estimate_sequence needs blocking calls: the sequence is in split-phase mode "
                            "(set_split_phase(False) first, or drive it with wait() like sequence._interleaved)")
     frac = float(MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
-    params = seq.gme_begin(frame_distance, int(BBME_BLOCK_SIZE), procedure, search_window)   # float32[P,6]
-    for level in (1, 2):
-        params[:, 0] = params[:, 0] * 2            # parameter_projection, in the array's own dtype
-        params[:, 3] = params[:, 3] * 2
-        params = _solve_batch(seq.gme_fit(level, params.astype(np.float64), frac))
-    return params
+    # first parameters -> projection -> level-1 fit stay on the device (gme_seq_gme_begin_fit); the host solves level 1,
+    # projects (in float64, the solution's dtype) and asks for level 2
+    _, sums = seq.gme_begin_fit(frame_distance, int(BBME_BLOCK_SIZE), frac, procedure, search_window)
+    params = _solve_batch(sums)
+    params[:, 0] = params[:, 0] * 2                # parameter_projection
+    params[:, 3] = params[:, 3] * 2
+    return _solve_batch(seq.gme_fit(2, params, frac))
 
 
 def global_motion_estimation(previous, current):

@@ -71,12 +71,11 @@ def estimate_sequence(seq, frame_distance=1, model="affine", procedure=3, search
     if getattr(seq, "_split", False):
         raise RuntimeError("estimate_sequence needs blocking calls: the sequence is in split-phase mode")
     frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
-    params = seq.gme_begin(frame_distance, int(motion.BBME_BLOCK_SIZE), procedure, search_window)
-    for level in (1, 2):
-        params[:, 0] = params[:, 0] * 2
-        params[:, 3] = params[:, 3] * 2
-        params = solve_model(seq.gme_fit(level, params.astype(np.float64), frac), model)
-    return params
+    _, sums = seq.gme_begin_fit(frame_distance, int(motion.BBME_BLOCK_SIZE), frac, procedure, search_window)
+    params = solve_model(sums, model)
+    params[:, 0] = params[:, 0] * 2
+    params[:, 3] = params[:, 3] * 2
+    return solve_model(seq.gme_fit(2, params, frac), model)
 
 
 def global_motion_estimation(previous, current, model="affine"):

@@ -444,15 +444,14 @@ class ShardedSequence:
         for lane in lanes:
             lane.seq.set_split_phase(True)
         try:
-            pending = [lane.seq.gme_begin(self.fd, bs, procedure, search_window) for lane in lanes]
-            for level in (1, 2):
-                for k, lane in enumerate(lanes):
-                    lane.seq.wait()
-                    # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
-                    p = np.array(pending[k]) if level == 1 else motion._solve_batch(pending[k])
-                    p[:, 0] = p[:, 0] * 2
-                    p[:, 3] = p[:, 3] * 2
-                    pending[k] = lane.seq.gme_fit(level, p.astype(np.float64), frac)
+            # first parameters, their projection and the level-1 fit in one queued call (gme_seq_gme_begin_fit)
+            pending = [lane.seq.gme_begin_fit(self.fd, bs, frac, procedure, search_window)[1] for lane in lanes]
+            for k, lane in enumerate(lanes):
+                lane.seq.wait()
+                p = motion._solve_batch(pending[k])        # level 1 solved, projected in float64, level 2 asked for
+                p[:, 0] = p[:, 0] * 2
+                p[:, 3] = p[:, 3] * 2
+                pending[k] = lane.seq.gme_fit(2, p, frac)
             params, sse = [None] * len(lanes), [None] * len(lanes)
             for k, lane in enumerate(lanes):
                 lane.seq.wait()
@@ -551,7 +550,7 @@ class StreamEstimator:
 
     def schedule(self, n_pairs):
         """Chunks [(first pair, end pair)] of a video of `n_pairs` pairs: as large as a lane holds while much is left (each
-        chunk costs the host four round trips whatever its size), shrinking towards the end -- a quarter of what is left per
+        chunk costs the host three round trips whatever its size), shrinking towards the end -- a quarter of what is left per
         lane, at least `min_chunk` -- because the estimate of the LAST chunk is the one stretch no upload hides (traced:
         with equal chunks of 1024 pairs the link idles 2.5 of 15.9 ms behind the last copy, with equal chunks of 128 the
         host's round trips leave gaps between the copies)."""
@@ -591,21 +590,25 @@ class StreamEstimator:
                 src = lane.host[:n]
             lane.seq.set_frames(n)               # the stages cover this chunk's pairs only; buffers stay sized for `cap`
             lane.seq.upload(0, src)              # queued; `src` stays alive (lane.host / the caller's array)
-            lane.pending = lane.seq.gme_begin(fd, bs, self.procedure, self.search_window)
+            # Nothing else is queued on the lane yet: a kernel launch behind a cross-stream wait on a copy holds the calling
+            # thread until that copy is done (measured: one gme_begin_fit call of 7.6 ms, the upload of two chunks), and the
+            # one host thread must stay free for the other lanes.  Stage 1 ends when the upload's event has arrived.
 
         def advance(lane):
             """Take the lane's result (it has arrived) and queue its next stage -> True when the chunk is finished."""
             seq, (p0, p1) = lane.seq, lane.chunk
             n = p1 - p0
             seq.wait()
-            if lane.stage in (1, 2):
-                level = lane.stage
-                # level 1 projects the float32 first parameters in float32, level 2 the float64 solution in float64
-                p = np.array(lane.pending[:n]) if level == 1 else solve(lane.pending[:n])
+            if lane.stage == 1:                  # the chunk is on the device: dense field, first parameters, level-1 fit
+                lane.pending = seq.gme_begin_fit(fd, bs, frac, self.procedure, self.search_window)[1]
+                lane.stage = 2
+                return False
+            if lane.stage == 2:                  # level-1 sums are back: solve, project (float64), ask for level 2
+                p = solve(lane.pending[:n])
                 p[:, 0] = p[:, 0] * 2
                 p[:, 3] = p[:, 3] * 2
-                lane.pending = seq.gme_fit(level, p, frac)
-                lane.stage += 1
+                lane.pending = seq.gme_fit(2, p, frac)
+                lane.stage = 3
                 return False
             if lane.stage == 3:
                 lane.params = solve(lane.pending[:n])
@@ -639,7 +642,8 @@ class StreamEstimator:
                         else:
                             busy.remove(lane)
             if not progressed:
-                max(busy, key=lambda l: l.stage).seq.wait()      # nothing ready: sleep until the most advanced lane is
+                time.sleep(2e-5)                 # nothing ready: look again shortly (blocking on ONE lane's event would sit out
+                                                 # another lane's result: traced, a lane idled 3.5 ms behind its finished upload)
         for lane in self.lanes:
             lane.ctx.sync()                      # drains the lane and reports a walk that overran its guard
         return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)

@@ -161,6 +161,12 @@ GME_API int gme_seq_gme_begin(gme_seq *seq, int frame_distance, int bbme_block_s
                       int search_window, float *params0_out);
 GME_API int gme_seq_gme_fit(gme_seq *seq, int level, const double *params_in, double outlier_fraction,
                     double *sums_out);
+/* begin + projection of the first parameters (motion.py:191-207: two exact doublings of the float32 vector) + fit(level 1) in
+ * one call: the first parameters go from the dense field to the level-1 fit on the device, so a staged run needs three
+ * dependent host round trips instead of four (level-1 sums, level-2 sums, squared errors).  Returns the level-1 sums
+ * (split-phase: once gme_seq_wait has returned) with the level-2 search already queued.  params0_out may be NULL. */
+GME_API int gme_seq_gme_begin_fit(gme_seq *seq, int frame_distance, int bbme_block_size, int procedure, int search_window,
+                          double outlier_fraction, float *params0_out, double *sums1_out);
 /* stage read-back for parity tests; any pointer may be NULL.
  * level 0: gt = dense field (bs 2); levels 1, 2: gt, model (int16), mask, threshold */
 GME_API int gme_seq_gme_read_stage(gme_seq *seq, int level, int pair, int32_t *gt, int16_t *model,

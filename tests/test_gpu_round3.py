@@ -112,6 +112,41 @@ def test_split_phase_upload_and_pageable_result_buffers(native, monkeypatch):
     seq.close()
 
 
+def test_begin_fit_equals_staged_calls(native):
+    """gme_seq_gme_begin_fit (first parameters -> projection -> level-1 fit on the device) hands back exactly what
+    gme_seq_gme_begin + the host's float32 projection + gme_seq_gme_fit(1) do: first parameters and level-1 sums bit for
+    bit, and the run continues into level 2 the same way -- blocking and split-phase, diamond and exhaustive level searches."""
+    import motion
+    import synth
+    ctx = native.default_context()
+    seq = native.Sequence(ctx, 9, 240, 368)
+    seq.upload(0, synth.sequence(77, 2, 9, 240, 368))
+    for proc, sw in ((3, 2), (0, 8)):
+        p0 = np.array(seq.gme_begin(1, 16, proc, sw))
+        proj = p0.copy()
+        proj[:, 0] *= 2
+        proj[:, 3] *= 2
+        sums1 = np.array(seq.gme_fit(1, proj.astype(np.float64), 0.3))
+        for split in (False, True):
+            seq.invalidate_pyramids()
+            seq.set_split_phase(split)
+            q0, t1 = seq.gme_begin_fit(1, 16, 0.3, proc, sw)
+            if split:
+                seq.wait()
+            assert np.array_equal(q0, p0) and np.array_equal(np.array(t1).view(np.uint64), sums1.view(np.uint64)), (proc, split)
+            p = motion._solve_batch(t1)
+            p[:, 0] *= 2
+            p[:, 3] *= 2
+            t2 = seq.gme_fit(2, p, 0.3)
+            if split:
+                seq.wait()
+            t2 = np.array(t2)
+            seq.set_split_phase(False)
+        want = motion.estimate_sequence(seq, 1, proc, sw)
+        assert np.array_equal(motion._solve_batch(t2), want), proc
+    seq.close()
+
+
 def test_set_frames_limits_the_stages(native):
     """gme_seq_set_frames: a sequence created for 12 frames acts as one of 5, then 9, then 12 -- block matching, the staged
     estimate and the compensation cover exactly the pairs of the frames in use and equal a fresh sequence of that length."""
