@@ -339,6 +339,27 @@ def test_comm_init_is_decided_by_all_ranks(tmp_path, scenario):
         assert all("comm=False" in outs[r] for r in range(3)), outs              # ranks 0 and 2 gave theirs back
 
 
+def test_committed_profiles_belong_to_these_kernels():
+    """bench.py prints `roofline.traffic` and the `issue` object only from a committed PMC summary taken with the SAME
+    kernel sources (kernel_source_sha).  A change under csrc/ without re-running tools/final_run.sh ... prof would turn
+    them into `null` in the driver's bench line: this test says so first.  One summary per BASELINE config and the walk
+    searches, each naming the kernel the launch plan names."""
+    sys.path.insert(0, REPO)
+    import bench
+    sha = bench.kernel_source_sha()
+    plans = {"exh720": "k_exh_sea16p<3,5>", "exh720mse": "k_exh_sea16p_mse<3,5>", "exh1080": "k_exh_sea16p<5,7>",
+             "exh1080mse": "k_exh_sea16p_mse<5,7>", "gme720": "k_walk16<1>", "gme1080exh": "k_exh_sea16p_mse<5,7>",
+             "tss720": "k_walk16s<1,1>", "tdl720": "k_walk16s<1,2>", "dia720mse": "k_walk16<1>"}
+    for config, kernel in plans.items():
+        vals, psha, name = bench.committed_profile(config, kernel)
+        assert name and psha == sha, "profiles/%s was taken with other kernel sources (%s != %s): re-run tools/final_run.sh <tag> prof" % (name, psha, sha)
+        assert vals["_kernel"].split("<")[0] == kernel.split("<")[0], (config, vals.get("_kernel"))
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+            assert vals.get(counter, 0) > 0, (config, counter)
+        stats = os.path.join(REPO, "profiles", name.replace("_pmc_summary.txt", "_kernel_stats.csv"))
+        assert os.path.exists(stats) and kernel.split("<")[0] in open(stats).read(), stats
+
+
 def test_stream_schedule_covers_every_pair_once():
     """StreamEstimator.schedule: chunks no larger than a lane holds, shrinking towards the end (the last chunk's estimate is
     the stretch no upload hides), never below min_chunk except for the remainder, every pair exactly once."""
