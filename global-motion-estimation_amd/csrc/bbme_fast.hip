@@ -420,7 +420,10 @@ __global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
 //   S(y)   = S(y-1) + h(y+15) - h(y-1), the last 16 h vectors held in a register ring (the row
 //            loop is unrolled in groups of 16 so that the ring indices are compile-time).
 // Each chunk re-walks 15 warm-up rows (1 byte per pixel, cheap next to the 4-byte outputs).
-constexpr int SQ_CHUNK = 32;
+#ifndef SQ_CHUNK_ROWS
+#define SQ_CHUNK_ROWS 64
+#endif
+constexpr int SQ_CHUNK = SQ_CHUNK_ROWS;
 
 __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch)
 {
@@ -443,6 +446,10 @@ __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch
     return out;
 }
 
+// Round 3: no register ring.  Round 2 kept the last 16 row vectors h in 64 VGPRs (152 in all: 3 waves per SIMD, and a
+// write-bound kernel at 3.4 TB/s with nobody to cover its latencies); the row that leaves the window, h(y - 1), is now
+// recomputed from a second read of that source row (16 rows back in the same thread's walk: L2 hits) -- twice the vector
+// work of a kernel that was 26 % VALU-busy, a quarter of the registers.
 __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long src_stride, int H, int W, int pitch,
                                                  uint32_t* dst, long long dst_stride)
 {
@@ -451,25 +458,17 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
     if (x > W - 16 || y0 > H - 16) return;
     const uint8_t* p = src + (long long)blockIdx.z * src_stride + (long long)y0 * pitch + x;
     uint32_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y0 * pitch + x;
-    u32x4_v ring[16], s = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int r = 0; r < 15; ++r) {                       // rows y0 .. y0+14 <= H-2
-        ring[r] = sq_hsum4(p + (long long)r * pitch, x, pitch);
-        s += ring[r];
-    }
+    u32x4_v s = { 0, 0, 0, 0 };
+#pragma unroll 5
+    for (int r = 0; r < 15; ++r) s += sq_hsum4(p + (long long)r * pitch, x, pitch);        // rows y0 .. y0+14 <= H-2
     const int last = min(SQ_CHUNK - 1, H - 16 - y0);     // last output row of this chunk
-    for (int kb = 0; kb <= last; kb += 16) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = kb + u;
-            if (k <= last) {
-                const u32x4_v h = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);   // row y0+k+15 <= H-1
-                s += h;
-                *(u32x4_v*)(o + (long long)k * pitch) = s;
-                s -= ring[u];                            // h(y0 + k): row r lives in ring[r & 15]
-                ring[(u + 15) & 15] = h;
-            }
-        }
+#pragma unroll 2
+    for (int k = 0; k <= last; ++k) {
+        const u32x4_v hn = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);            // row y0+k+15 <= H-1 enters
+        const u32x4_v ho = sq_hsum4(p + (long long)k * pitch, x, pitch);                   // row y0+k leaves behind this output
+        s += hn;
+        *(u32x4_v*)(o + (long long)k * pitch) = s;
+        s -= ho;
     }
 }
 
