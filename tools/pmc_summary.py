@@ -22,7 +22,14 @@ try:
     print("# kernel_source_sha: %s" % bench.kernel_source_sha())       # bench.py emits these counters only for the same kernels
 except Exception as e:      # noqa: BLE001
     print("# kernel_source_sha: unknown (%r)" % (e,))
-for path in sorted(glob.glob(root + "/pmc_*/*/*_counter_collection.csv")):
+# gpurun merges a call's files INTO the local gpurun_out/: a pass directory re-used by a later profile run holds the CSVs of
+# the earlier runs (other builds) as well -- only the newest CSV of each pass directory is this build's
+newest = {}
+for path in glob.glob(root + "/pmc_*/*/*_counter_collection.csv"):
+    d = os.path.dirname(path)
+    if d not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d]):
+        newest[d] = path
+for path in sorted(newest.values()):
     agg = collections.defaultdict(list)
     bygrid = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
