@@ -467,7 +467,9 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
         const u32x4_v hn = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);            // row y0+k+15 <= H-1 enters
         const u32x4_v ho = sq_hsum4(p + (long long)k * pitch, x, pitch);                   // row y0+k leaves behind this output
         s += hn;
-        *(u32x4_v*)(o + (long long)k * pitch) = s;
+        // non-temporal: the 4-byte-per-pixel output stream would otherwise push the source rows out of the L2 before
+        // their second read 16 rows later (same box: 315.2 k -> 319.3 k pairs/s exhaustive MSE, 30.45 k -> 30.8 k at 1080p)
+        __builtin_nontemporal_store(s, (u32x4_v*)(o + (long long)k * pitch));
         s -= ho;
     }
 }

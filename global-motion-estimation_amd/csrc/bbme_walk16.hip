@@ -109,6 +109,23 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
 constexpr int WIN_ROWS = 40, WIN_DW = 12, WIN_PITCH = 13, WIN_SPAN = 4 * (WIN_DW - 5) + 3;
 constexpr int WIN_ALLOC = 43 * WIN_PITCH;      // staging moves 128 sixteen-byte segments (2 per lane, no idle lanes): 42 2/3 rows
 
+// Two window geometries.  Win<false> (the constants above) is the diamond walk's: patterns reach 2 pixels, the window
+// follows the walk.  Win<true> is the one of three-step and 2-D log (round 3): 48 rows x 64 bytes (192 segments, 3 per
+// lane, pitch 17 dwords: odd, so the 8 lanes of a group still hit 8 banks) hold a pattern of span 32 -- the first step
+// of both searches at sw = 16 -- so that round is served from the LDS as well instead of reading global memory through
+// unaligned loads, and the later, narrower rounds usually fall inside the same window: one staging per block.
+#ifndef WALK_SMALLWIN
+constexpr bool WALK_BIG = true;
+#else
+constexpr bool WALK_BIG = false;
+#endif
+template <bool BIG> struct Win {
+    static constexpr int ROWS = BIG ? 48 : WIN_ROWS, DW = BIG ? 16 : WIN_DW, PITCH = BIG ? 17 : WIN_PITCH;
+    static constexpr int SPAN = 4 * (DW - 5) + 3;
+    static constexpr int SEGS_ROW = BIG ? 4 : 3, SEGS_LANE = BIG ? 3 : 2;
+    static constexpr int ALLOC = BIG ? 48 * 17 : WIN_ALLOC;
+};
+
 // Window staging in two halves, so that the loads of a block's first window can be in flight while the
 // wave still walks the block before it: 3 sixteen-byte segments per row, 2 segments per lane.
 // buffer resource over one H x pitch plane plus `slack` bytes (pointer and size wave-uniform)
@@ -121,7 +138,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const uint8_t* plan
         (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-__device__ __forceinline__ void window_load(uint32_t (&v)[2][4], const uint8_t* cur, int pitch, int H, int wr0, int wc0,
+template <bool BIG = false>
+__device__ __forceinline__ void window_load(uint32_t (&v)[Win<BIG>::SEGS_LANE][4], const uint8_t* cur, int pitch, int H, int wr0, int wc0,
                                             int lane)
 {
     // Branch-free through a buffer resource over the plane: whatever lies outside [0, H * pitch) -- rows above or
@@ -134,33 +152,35 @@ __device__ __forceinline__ void window_load(uint32_t (&v)[2][4], const uint8_t* 
     // last row is not dropped as a whole; every plane has a guard row behind it (plane_alloc, gme_bbme_u8).
     const __amdgpu_buffer_rsrc_t rs = plane_rsrc(cur, H * pitch + 12);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < Win<BIG>::SEGS_LANE; ++it) {
         const int seg = lane + 64 * it;
-        const int row = seg / 3, s4 = seg - row * 3;
+        const int row = seg / Win<BIG>::SEGS_ROW, s4 = seg - row * Win<BIG>::SEGS_ROW;
         const int off = __mul24(wr0 + row, pitch) + wc0 + 16 * s4;           // negative = far out of range as unsigned
         const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
     }
 }
 
-__device__ __forceinline__ void window_store(uint32_t* lds, const uint32_t (&v)[2][4], int lane)
+template <bool BIG = false>
+__device__ __forceinline__ void window_store(uint32_t* lds, const uint32_t (&v)[Win<BIG>::SEGS_LANE][4], int lane)
 {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int seg = lane + 64 * it;                 // 128 segments = the 40 window rows + 8 spare segments (WIN_ALLOC)
-        const int row = seg / 3, s4 = seg - row * 3;
-        uint32_t* o = lds + row * WIN_PITCH + 4 * s4;
+    for (int it = 0; it < Win<BIG>::SEGS_LANE; ++it) {
+        const int seg = lane + 64 * it;                 // small: 128 segments = the 40 window rows + 8 spare segments (WIN_ALLOC)
+        const int row = seg / Win<BIG>::SEGS_ROW, s4 = seg - row * Win<BIG>::SEGS_ROW;
+        uint32_t* o = lds + row * Win<BIG>::PITCH + 4 * s4;
         o[0] = v[it][0]; o[1] = v[it][1]; o[2] = v[it][2]; o[3] = v[it][3];
     }
     __builtin_amdgcn_wave_barrier();                    // LDS ops of one wave complete in order
 }
 
+template <bool BIG = false>
 __device__ __forceinline__ void stage_walk_window(uint32_t* lds, const uint8_t* cur, int pitch, int H, int wr0,
                                                   int wc0, int lane)
 {
-    uint32_t v[2][4];
-    window_load(v, cur, pitch, H, wr0, wc0, lane);
-    window_store(lds, v, lane);
+    uint32_t v[Win<BIG>::SEGS_LANE][4];
+    window_load<BIG>(v, cur, pitch, H, wr0, wc0, lane);
+    window_store<BIG>(lds, v, lane);
 }
 
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
@@ -171,7 +191,7 @@ __device__ __forceinline__ int lds_address(const uint32_t* p)       // byte addr
 }
 
 // cost of the candidate whose two rows for this lane start at LDS byte address `addr` (shift sh inside the dword)
-template <int PNORM>
+template <int PNORM, int PITCH = WIN_PITCH>
 __device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsigned aa, int addr, uint32_t sh, bool valid)
 {
     unsigned part = 0;
@@ -179,7 +199,7 @@ __device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsign
         lds_u32* p = (lds_u32*)(uint32_t)addr;
         uint32_t l0[5], l1[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[WIN_PITCH + j]; }
+        for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[PITCH + j]; }
         uint32_t b[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -210,18 +230,23 @@ static_assert(4 * WIN_PITCH == 52, "row pitch in bytes is spelled out in the asm
 // byte offset of candidate (rr, cc)'s rows lrow, lrow + 1 in the window.  Window origin columns are multiples of 4
 // (wc0 = ... & ~3), so the byte shift is cc & 3 and the dword column (cc & ~3) - wc0; everything wave-uniform
 // (window origin: sbase = -wr0 * row bytes - wc0) folds into one scalar: mad24 + and + add
+template <int PITCH = WIN_PITCH>
 __device__ __forceinline__ int window_offset(int sbase, int rr, int cc, int lrow52)
 {
     int rowoff;                                              // valid candidates have 0 <= rr < 2^24; asm keeps the compiler
-    asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow52));   // from re-deriving a v_mul_lo_u32
+    if (PITCH == WIN_PITCH)                                  // from re-deriving a v_mul_lo_u32
+        asm("v_mad_u32_u24 %0, %1, 52, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow52));
+    else                                                     // 68 is no inline constant: the row bytes come in an SGPR
+        asm("v_mad_u32_u24 %0, %1, %3, %2" : "=v"(rowoff) : "v"(rr), "v"(lrow52), "s"(4 * PITCH));
     return rowoff + ((cc & ~3) + sbase);
 }
 
-template <int PNORM>
+template <int PNORM, bool BIG = false>
 __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsigned aa, const uint32_t* lds, int sbase,
                                                    int rr, int cc, bool valid, int lrow)
 {
-    return group_eval_at<PNORM>(a, aa, window_offset(sbase + lds_address(lds), rr, cc, lrow * (4 * WIN_PITCH)), (uint32_t)cc & 3u, valid);
+    constexpr int P = Win<BIG>::PITCH;
+    return group_eval_at<PNORM, P>(a, aa, window_offset<P>(sbase + lds_address(lds), rr, cc, lrow * (4 * P)), (uint32_t)cc & 3u, valid);
 }
 
 // minimum of one key per 8-lane group (every lane of a group holds its group's key) -> wave-uniform: one DPP rotate
@@ -235,13 +260,14 @@ __device__ __forceinline__ unsigned groups_min(unsigned key)
     return (unsigned)__builtin_amdgcn_readlane((int)key, 63);
 }
 
-// range of the valid ones among the three positions org - st, org, org + st of one axis (valid: 0 <= v <= limit);
-// lo > hi when none is
-__device__ __forceinline__ void axis_range3(int org, int st, int limit, int& lo, int& hi)
+// the part of [org - st, org + st] inside [0, limit]: holds every valid one of the three positions org - st, org,
+// org + st of one axis (valid: 0 <= v <= limit); lo > hi when none of them is.  It may start before the first valid
+// position (org - st < 0 <= org: the box starts at 0, not at org) -- the box only places the LDS window, which then
+// covers a few rows more than it had to; two scalar instructions per bound instead of the fourteen of the exact range.
+__device__ __forceinline__ void axis_box(int org, int st, int limit, int& lo, int& hi)
 {
-    const bool v0 = org - st >= 0 && org - st <= limit, v1 = org >= 0 && org <= limit, v2 = org + st >= 0 && org + st <= limit;
-    lo = v0 ? org - st : v1 ? org : v2 ? org + st : 1 << 30;
-    hi = v2 ? org + st : v1 ? org : v0 ? org - st : -(1 << 30);
+    lo = max(org - st, 0);
+    hi = min(org + st, limit);
 }
 
 // What a wave fetches ahead for a block: its 2 anchor rows per lane and, for the diamond search (whose first
@@ -285,6 +311,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                                            const WalkPre& pre)
 {
     constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
+    constexpr bool SBIG = !DIA && WALK_BIG;                      // window geometry of this search (Win<>)
+    typedef Win<SBIG> WS;
     const long long gid = (long long)pair * nblk + blk;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const int lane = threadIdx.x & 63;
@@ -305,30 +333,35 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     // Candidates are served from the LDS window; when some fall outside it the window is moved
     // (centred on their bounding box) and, if the pattern is wider than the window (first steps
     // of three-step / 2-D log), this round reads global memory directly.
-    int wr0 = 0, wc0 = 0;
-    bool have_win = false;
+    int wr0 = -(1 << 20), wc0 = 0;                  // far away: nothing staged yet (the diamond walk sets its first window itself)
 #if defined(WALK_ABLATE) && WALK_ABLATE == 1      // timing experiments only (tools/build_variant.sh): anchors loaded, nothing else
     if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)(a[0] + a[7] + aa) >> 30; o[1] = 0; }
     return;
 #endif
     // cost of this lane's group's candidate (RR, CC, OK: per-lane values, equal inside a group) -> COST in every lane of
-    // the group (INF32 if !OK).  [RMIN, RMAX] x [CMIN, CMAX] is the wave-uniform bounding box of the round's valid
+    // the group (INF32 if !OK).  [RMIN, RMAX] x [CMIN, CMAX] is a wave-uniform box that holds the round's valid
     // candidates (RMIN > RMAX: none): when it fits, the round is served from the LDS window, which is moved (centred on
     // the box) if it does not cover it; a pattern wider than the window (first steps of three-step / 2-D log) reads
     // global memory directly.
+    // Round 3: these kernels were bound by the SCALAR unit (2-D log: 2.3 scalar instructions per vector instruction,
+    // scalar issue 0.96 busy; profiles/r03_final_tdl720_pmc_summary.txt) -- wave-uniform booleans cost the compiler an
+    // s_cmp + s_cselect_b64 each and an s_and_b64 per conjunction.  The tests are therefore sign tests of ORed
+    // differences: "inside the staged window" is dr, rs - dr, dc, cs - dc all >= 0 (rs, cs: the slack of the box in a
+    // window), "fits a window" is rs, cs - 3 >= 0 for a non-empty box; one s_or chain and one compare each.
 #define EVALV(RR, CC, OK, RMIN, RMAX, CMIN, CMAX, COST)                                               \
     do {                                                                                             \
-        bool lds_ok_ = (RMAX) >= (RMIN) && (CMAX) >= (CMIN);                                         \
-        if (lds_ok_ && !(have_win && (RMIN) >= wr0 && (RMAX) <= wr0 + WIN_ROWS - 16 && (CMIN) >= wc0 && \
-                         (CMAX) <= wc0 + WIN_SPAN)) {                                                \
-            if ((RMAX) - (RMIN) <= WIN_ROWS - 16 && (CMAX) - (CMIN) <= WIN_SPAN - 3) {               \
-                wr0 = (RMIN) - (WIN_ROWS - 16 - ((RMAX) - (RMIN))) / 2;                              \
-                wc0 = max(0, ((CMIN) - (WIN_SPAN - 3 - ((CMAX) - (CMIN))) / 2) & ~3);                \
-                stage_walk_window(win, cur, pitch, H, wr0, wc0, lane);                               \
-                have_win = true;                                                                     \
+        const int rh_ = (RMAX) - (RMIN), ch_ = (CMAX) - (CMIN);                                      \
+        const int rs_ = (WS::ROWS - 16) - rh_, cs_ = WS::SPAN - ch_;                                 \
+        const int dr_ = (RMIN) - wr0, dc_ = (CMIN) - wc0;                                            \
+        bool lds_ok_ = true;                                                                         \
+        if ((dr_ | (rs_ - dr_) | dc_ | (cs_ - dc_)) < 0) {                                           \
+            if ((rh_ | ch_ | rs_ | (cs_ - 3)) >= 0) {                                                \
+                wr0 = (RMIN) - (rs_ >> 1);                                                           \
+                wc0 = max(0, ((CMIN) - ((cs_ - 3) >> 1)) & ~3);                                      \
+                stage_walk_window<SBIG>(win, cur, pitch, H, wr0, wc0, lane);                         \
             } else lds_ok_ = false;                                                                  \
         }                                                                                            \
-        COST = lds_ok_ ? group_eval_lds<PNORM>(a, aa, win, -wr0 * (4 * WIN_PITCH) - wc0, RR, CC, OK, lrow)  \
+        COST = lds_ok_ ? group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow)  \
                        : group_eval<PNORM>(a, aa, cur, pitch, RR, CC, OK, lrow);                     \
     } while (0)
 
@@ -467,8 +500,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         for (int s = 0; s < 3; ++s) {
             const int st = s == 0 ? d.st1 : s == 1 ? d.st2 : d.st3;
             int rmin, rmax, cmin, cmax;
-            axis_range3(org_r, st, H - 16, rmin, rmax);
-            axis_range3(org_c, st, W - 16, cmin, cmax);
+            axis_box(org_r, st, H - 16, rmin, rmax);
+            axis_box(org_c, st, W - 16, cmin, cmax);
             unsigned key;
             {
                 const int rr = org_r + ur * st, cc = org_c + uc * st;
@@ -504,8 +537,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         while (step > 1) {
             const bool cross = step > 2;
             int rmin, rmax, cmin, cmax;
-            axis_range3(pr, cross ? step : 2, H - 16, rmin, rmax);
-            axis_range3(pc, cross ? step : 2, W - 16, cmin, cmax);
+            axis_box(pr, cross ? step : 2, H - 16, rmin, rmax);
+            axis_box(pc, cross ? step : 2, W - 16, cmin, cmax);
             unsigned key;
             {
                 const int rr = pr + (cross ? xr * step : gr * 2), cc = pc + (cross ? xc * step : gc * 2);
@@ -543,8 +576,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 
 // Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
 // dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
-template <int PNORM, int PROC>
-__device__ __forceinline__ void walk16_workgroup(const WalkDev& d, uint32_t (&win_all)[4][WIN_ALLOC])
+template <int PNORM, int PROC, int ALLOC>
+__device__ __forceinline__ void walk16_workgroup(const WalkDev& d, uint32_t (&win_all)[4][ALLOC])
 {
     constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -578,14 +611,14 @@ template <int PNORM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_walk16(WalkDev d)
 {
     __shared__ uint32_t win_all[4][WIN_ALLOC];
-    walk16_workgroup<PNORM, GME_SEARCH_DIAMOND>(d, win_all);
+    walk16_workgroup<PNORM, GME_SEARCH_DIAMOND, WIN_ALLOC>(d, win_all);
 }
 
 template <int PNORM, int PROC>
 __global__ void __launch_bounds__(256) k_walk16s(WalkDev d)
 {
-    __shared__ uint32_t win_all[4][WIN_ALLOC];
-    walk16_workgroup<PNORM, PROC>(d, win_all);
+    __shared__ uint32_t win_all[4][Win<WALK_BIG>::ALLOC];
+    walk16_workgroup<PNORM, PROC, Win<WALK_BIG>::ALLOC>(d, win_all);
 }
 
 // ---------------------------------------------------------------------------
