@@ -505,14 +505,14 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             unsigned key;
             {
                 const int rr = org_r + ur * st, cc = org_c + uc * st;
-                const bool ok = rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                const bool ok = (unsigned)rr <= (unsigned)(H - 16) && (unsigned)cc <= (unsigned)(W - 16);   // 0 <= v <= limit
                 unsigned c;
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
                 key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
             {
                 const int rr = org_r + st, cc = org_c + st;        // candidate 8 (wave-uniform), by group 0
-                const bool ok = grp == 0 && rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                const bool ok = grp == 0 && (unsigned)rr <= (unsigned)(H - 16) && (unsigned)cc <= (unsigned)(W - 16);
                 unsigned c;
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
                 key = min(key, ok ? (c << 4) | 8u : INF32);
@@ -534,20 +534,39 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         const int xc = grp == 3 ? 1 : grp == 4 ? -1 : 0;
         const int gr = grp / 3 - 1, gc = grp % 3 - 1;
         int br = 0, bc = 0, pr = r0, pc = c0, step = d.sw, it = 0;
-        while (step > 1) {
-            const bool cross = step > 2;
+        const unsigned rlim = (unsigned)(H - 16), clim = (unsigned)(W - 16);      // 0 <= v <= limit as one unsigned compare
+        // The cross rounds (step > 2) and the one ring round that ends the walk (step == 2: bbme.py halves the step after
+        // it whatever it found) are two pieces of code: no per-round selects between the two patterns.
+        while (step > 2) {
             int rmin, rmax, cmin, cmax;
-            axis_box(pr, cross ? step : 2, H - 16, rmin, rmax);
-            axis_box(pc, cross ? step : 2, W - 16, cmin, cmax);
+            axis_box(pr, step, H - 16, rmin, rmax);
+            axis_box(pc, step, W - 16, cmin, cmax);
+            const int rr = pr + xr * step, cc = pc + xc * step;
+            const bool ok = grp < 5 && (unsigned)rr <= rlim && (unsigned)cc <= clim;
+            unsigned c;
+            EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+            const unsigned kmin = groups_min(ok ? (c << 4) | (unsigned)grp : INF32);
+            if (kmin != INF32) {                                    // the centre is always valid, so this always holds
+                const int k = (int)(kmin & 15u);
+                br = pr + (k == 1 ? step : k == 2 ? -step : 0); bc = pc + (k == 3 ? step : k == 4 ? -step : 0);
+            }
+            if (br == pr && bc == pc) step /= 2;
+            pr = br; pc = bc;
+            if (++it > cap) { overrun = true; break; }
+        }
+        if (step == 2 && !overrun) {
+            int rmin, rmax, cmin, cmax;
+            axis_box(pr, 2, H - 16, rmin, rmax);
+            axis_box(pc, 2, W - 16, cmin, cmax);
             unsigned key;
             {
-                const int rr = pr + (cross ? xr * step : gr * 2), cc = pc + (cross ? xc * step : gc * 2);
-                const bool ok = (!cross || grp < 5) && rr >= 0 && cc >= 0 && rr <= H - 16 && cc <= W - 16;
+                const int rr = pr + gr * 2, cc = pc + gc * 2;
+                const bool ok = (unsigned)rr <= rlim && (unsigned)cc <= clim;
                 unsigned c;
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
                 key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
-            if (!cross) {
+            {
                 const int rr = pr + 2, cc = pc + 2;
                 const bool ok = grp == 0 && rr <= H - 16 && cc <= W - 16;        // pr, pc >= 0
                 unsigned c;
@@ -555,14 +574,11 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                 key = min(key, ok ? (c << 4) | 8u : INF32);
             }
             const unsigned kmin = groups_min(key);
-            if (kmin != INF32) {                                    // the centre is always valid, so this always holds
+            if (kmin != INF32) {
                 const int k = (int)(kmin & 15u);
-                if (cross) { br = pr + (k == 1 ? step : k == 2 ? -step : 0); bc = pc + (k == 3 ? step : k == 4 ? -step : 0); }
-                else { br = pr + (k / 3 - 1) * 2; bc = pc + (k % 3 - 1) * 2; }
+                br = pr + (k / 3 - 1) * 2; bc = pc + (k % 3 - 1) * 2;
             }
-            if ((br == pr && bc == pc) || step == 2) step /= 2;
-            pr = br; pc = bc;
-            if (++it > cap) { overrun = true; break; }
+            if (++it > cap) overrun = true;
         }
         out1 = br - r0; out0 = bc - c0;
     }
