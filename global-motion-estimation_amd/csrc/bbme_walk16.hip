@@ -15,8 +15,10 @@
 //                     the winner in the vector unit (PATTERN_MIN), 41 vector + ~35 scalar instructions
 //                     per round of 8 candidates under MSE.  Three-step and 2-D log are instances of their own
 //                     (PROC): every group derives its candidate from its index, validity is a per-lane test, the
-//                     round's bounding box comes from the separable row / column validity (EVALV) and the winner
-//                     from the same DPP minimum -- no wave-uniform candidate arrays, no scalar spills.
+//                     round's box is the pattern's span clipped to the frame (EVALV) and the winner comes
+//                     from the same DPP minimum -- no wave-uniform candidate arrays, no scalar spills.  Their LDS
+//                     window is 48 rows x 64 bytes (Win<true>): the first step of both searches at sw = 16 (span 32)
+//                     fits, so a block is usually staged once and never reads global memory directly.
 //   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
 //                     coarsest pyramid level, 5400 blocks per 720x480 pair).
 //
@@ -249,6 +251,31 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
     return group_eval_at<PNORM, P>(a, aa, window_offset<P>(sbase + lds_address(lds), rr, cc, lrow * (4 * P)), (uint32_t)cc & 3u, valid);
 }
 
+// cost of ONE candidate by all 64 lanes together, wave-uniform result: lane l takes dword l % 4 of block row l / 4 (two
+// window dwords, one v_alignbyte, one v_sad_u8 or three v_dot4), 7 DPP adds leave the sum in lane 63.  `origin` = LDS
+// byte address of window cell (row 0, column 0) in frame coordinates (window base - wr0 * row bytes - wc0).  A third of
+// the instructions of a group round that would keep 7 of the 8 groups idle: the diamond's first centre, the ninth
+// candidate of a three-step step and of the 2-D log's last ring.
+template <int PNORM, int PITCH>
+__device__ __forceinline__ unsigned wave_eval_lds(uint32_t mine, int origin, int rr, int cc, int lane)
+{
+    lds_u32* p = (lds_u32*)(uint32_t)((lane >> 2) * (4 * PITCH) + 4 * (lane & 3) + (rr * (4 * PITCH) + (cc & ~3) + origin));
+    const uint32_t b = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)cc & 3u);
+    unsigned part;
+    if (PNORM == 0) {
+        part = __builtin_amdgcn_sad_u8(mine, b, 0u);
+    } else {
+        const unsigned bb = __builtin_amdgcn_udot4(b, b, __builtin_amdgcn_udot4(mine, mine, 0u, false), false);
+        const unsigned ab = __builtin_amdgcn_udot4(mine, b, 0u, false);
+        asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
+    }
+    part = group8_sum(part);
+    part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x128, 0xF, 0xF, false);     // row_ror 8: 16-lane rows
+    part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x142, 0xA, 0xF, false);     // row_bcast15 into rows 1, 3
+    part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x143, 0xC, 0xF, false);     // row_bcast31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)part, 63);
+}
+
 // minimum of one key per 8-lane group (every lane of a group holds its group's key) -> wave-uniform: one DPP rotate
 // inside each 16-lane row, rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31),
 // lane 63 ends with the minimum
@@ -275,7 +302,7 @@ __device__ __forceinline__ void axis_box(int org, int st, int limit, int& lo, in
 struct WalkPre {
     uint4 a0, a1;
     uint32_t w[2][4];
-    uint32_t mine;          // diamond: anchor dword (row lane / 4, dword lane % 4) for the all-lanes cost of the first centre
+    uint32_t mine;          // anchor dword (row lane / 4, dword lane % 4) for the all-lanes cost of one candidate (wave_eval_lds)
 };
 
 // first window of a diamond walk: the one PATTERN_MIN would stage around the clamped block origin
@@ -297,8 +324,8 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
     const u32x4_t t0 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff, 0, 0);
     const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + d.pitch, 0, 0);
     f.a0 = make_uint4(t0.x, t0.y, t0.z, t0.w); f.a1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
+    f.mine = __builtin_amdgcn_raw_buffer_load_b32(ra, __mul24(r0 + (lane >> 2), d.pitch) + c0 + 4 * (lane & 3), 0, 0);
     if (DIA) {
-        f.mine = __builtin_amdgcn_raw_buffer_load_b32(ra, __mul24(r0 + (lane >> 2), d.pitch) + c0 + 4 * (lane & 3), 0, 0);
         int wr0, wc0;
         first_window(d, blk, wr0, wc0);
         window_load(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, wr0, wc0, lane);
@@ -334,6 +361,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     // (centred on their bounding box) and, if the pattern is wider than the window (first steps
     // of three-step / 2-D log), this round reads global memory directly.
     int wr0 = -(1 << 20), wc0 = 0;                  // far away: nothing staged yet (the diamond walk sets its first window itself)
+    bool round_lds = false;                         // the last EVALV round was served from the LDS window
 #if defined(WALK_ABLATE) && WALK_ABLATE == 1      // timing experiments only (tools/build_variant.sh): anchors loaded, nothing else
     if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)(a[0] + a[7] + aa) >> 30; o[1] = 0; }
     return;
@@ -363,6 +391,22 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         }                                                                                            \
         COST = lds_ok_ ? group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow)  \
                        : group_eval<PNORM>(a, aa, cur, pitch, RR, CC, OK, lrow);                     \
+        round_lds = lds_ok_;                                                                         \
+    } while (0)
+    // the ninth candidate of a round (wave-uniform position inside the round's box): by all lanes from the window the
+    // round's first EVALV has just made sure of, else by group 0 like the other eight
+#define EVAL9(RR, CC, RMIN, RMAX, CMIN, CMAX, KEY)                                                    \
+    do {                                                                                             \
+        const bool ok9_ = (unsigned)(RR) <= (unsigned)(H - 16) && (unsigned)(CC) <= (unsigned)(W - 16);   \
+        if (ok9_ && round_lds) {                                                                     \
+            const unsigned c_ = wave_eval_lds<PNORM, WS::PITCH>(pre.mine, lds_address(win) - wr0 * (4 * WS::PITCH) - wc0, RR, CC, lane); \
+            KEY = min(KEY, (c_ << 4) | 8u);                                                          \
+        } else {                                                                                     \
+            const bool ok_ = grp == 0 && ok9_;                                                       \
+            unsigned c_;                                                                             \
+            EVALV(RR, CC, ok_, RMIN, RMAX, CMIN, CMAX, c_);                                          \
+            KEY = min(KEY, ok_ ? (c_ << 4) | 8u : INF32);                                            \
+        }                                                                                            \
     } while (0)
 
     int out0 = 0, out1 = 0;
@@ -420,22 +464,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             // dword l % 4 of block row l / 4 (two window dwords, one v_alignbyte with a scalar shift, one v_sad_u8 or
             // two v_dot4), then 7 DPP adds leave the cost in lane 63 -- a third of the instructions of a
             // pattern round that would keep 7 of the 8 groups idle.  The prefetched window is built around it.
-            lds_u32* p = (lds_u32*)(uint32_t)((lane >> 2) * (4 * WIN_PITCH) + 4 * (lane & 3) +
-                                              (qr * (4 * WIN_PITCH) + (qc & ~3) + sbase));
-            const uint32_t b = __builtin_amdgcn_alignbyte(p[1], p[0], (uint32_t)qc & 3u);
-            unsigned part;
-            if (PNORM == 0) {
-                part = __builtin_amdgcn_sad_u8(pre.mine, b, 0u);
-            } else {
-                const unsigned bb = __builtin_amdgcn_udot4(b, b, __builtin_amdgcn_udot4(pre.mine, pre.mine, 0u, false), false);
-                const unsigned ab = __builtin_amdgcn_udot4(pre.mine, b, 0u, false);
-                asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
-            }
-            part = group8_sum(part);
-            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x128, 0xF, 0xF, false);     // row_ror 8: 16-lane rows
-            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x142, 0xA, 0xF, false);     // row_bcast15 into rows 1, 3
-            part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x143, 0xC, 0xF, false);     // row_bcast31 into rows 2, 3
-            centre_cost = (unsigned)__builtin_amdgcn_readlane((int)part, 63);
+            centre_cost = wave_eval_lds<PNORM, WIN_PITCH>(pre.mine, sbase, qr, qc, lane);
         }
 #if defined(WALK_ABLATE) && WALK_ABLATE == 2      // first window staged + centre evaluated
         if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)centre_cost >> 30; o[1] = 0; }
@@ -510,13 +539,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
                 key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
-            {
-                const int rr = org_r + st, cc = org_c + st;        // candidate 8 (wave-uniform), by group 0
-                const bool ok = grp == 0 && (unsigned)rr <= (unsigned)(H - 16) && (unsigned)cc <= (unsigned)(W - 16);
-                unsigned c;
-                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
-                key = min(key, ok ? (c << 4) | 8u : INF32);
-            }
+            EVAL9(org_r + st, org_c + st, rmin, rmax, cmin, cmax, key);        // candidate 8 (wave-uniform position)
             const unsigned kmin = groups_min(key);
             int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;       // nothing valid: the stale offsets stay (bbme.py:332-336)
             if (kmin != INF32) {
@@ -566,13 +589,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
                 key = ok ? (c << 4) | (unsigned)grp : INF32;
             }
-            {
-                const int rr = pr + 2, cc = pc + 2;
-                const bool ok = grp == 0 && rr <= H - 16 && cc <= W - 16;        // pr, pc >= 0
-                unsigned c;
-                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
-                key = min(key, ok ? (c << 4) | 8u : INF32);
-            }
+            EVAL9(pr + 2, pc + 2, rmin, rmax, cmin, cmax, key);
             const unsigned kmin = groups_min(key);
             if (kmin != INF32) {
                 const int k = (int)(kmin & 15u);
@@ -582,6 +599,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         }
         out1 = br - r0; out0 = bc - c0;
     }
+#undef EVAL9
 #undef EVALV
     if (lane == 0) {
         if (overrun) atomicExch(d.status, 1);
