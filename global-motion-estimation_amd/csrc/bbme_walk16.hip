@@ -82,8 +82,8 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
         // but crawl through the texture addresser (measured 4x slower end to end)
         const uint8_t* p = cur + (long long)(rr + lrow) * pitch + (cc & ~3);
         const uint32_t sh = (uint32_t)cc & 3u;
-        const u32x4_a4 l0 = *(const u32x4_a4*)p, l1 = *(const u32x4_a4*)(p + pitch);
-        const uint32_t t0 = *(const uint32_t*)(p + 16), t1 = *(const uint32_t*)(p + pitch + 16);
+        const u32x4_a4 l0 = *(const u32x4_a4*)p, l1 = *(const u32x4_a4*)(p + 8 * pitch);
+        const uint32_t t0 = *(const uint32_t*)(p + 16), t1 = *(const uint32_t*)(p + 8 * pitch + 16);
         const uint32_t b[8] = { __builtin_amdgcn_alignbyte(l0.y, l0.x, sh), __builtin_amdgcn_alignbyte(l0.z, l0.y, sh),
                                 __builtin_amdgcn_alignbyte(l0.w, l0.z, sh), __builtin_amdgcn_alignbyte(t0, l0.w, sh),
                                 __builtin_amdgcn_alignbyte(l1.y, l1.x, sh), __builtin_amdgcn_alignbyte(l1.z, l1.y, sh),
@@ -192,7 +192,8 @@ __device__ __forceinline__ int lds_address(const uint32_t* p)       // byte addr
     return (int)(uint32_t)(uintptr_t)(lds_u32*)p;
 }
 
-// cost of the candidate whose two rows for this lane start at LDS byte address `addr` (shift sh inside the dword)
+// cost of the candidate whose rows lrow and lrow + 8 for this lane start at LDS byte address `addr` and 8 rows below it
+// (shift sh inside the dword)
 template <int PNORM, int PITCH = WIN_PITCH>
 __device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsigned aa, int addr, uint32_t sh, bool valid)
 {
@@ -201,7 +202,7 @@ __device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsign
         lds_u32* p = (lds_u32*)(uint32_t)addr;
         uint32_t l0[5], l1[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[PITCH + j]; }
+        for (int j = 0; j < 5; ++j) { l0[j] = p[j]; l1[j] = p[8 * PITCH + j]; }
         uint32_t b[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -276,6 +277,47 @@ __device__ __forceinline__ unsigned wave_eval_lds(uint32_t mine, int origin, int
     return (unsigned)__builtin_amdgcn_readlane((int)part, 63);
 }
 
+// Four candidates, one per 16-lane row, one block row per lane (the diamond's small pattern: a group round would leave
+// half of the wave idle).  A lane's two block rows are lrow and lrow + 8 (walk_block), so lane r of a 16-lane row already
+// holds block row r: in a[0..3] when r < 8, in a[4..7] otherwise -- `arow` is that choice, no data moves.  Five window
+// dwords, 4 v_alignbyte, 4 v_sad_u8 or 12 v_dot4, 4 DPP adds leave the candidate's cost in every lane of its row.
+template <int PNORM>
+__device__ __forceinline__ unsigned row16_eval_at(const uint32_t (&arow)[4], int addr, uint32_t sh)
+{
+    lds_u32* p = (lds_u32*)(uint32_t)addr;
+    uint32_t l[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) l[j] = p[j];
+    uint32_t b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = __builtin_amdgcn_alignbyte(l[j + 1], l[j], sh);
+    unsigned part = 0;
+    if (PNORM == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part = __builtin_amdgcn_sad_u8(arow[j], b[j], part);
+    } else {
+        unsigned bb = 0, ab = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bb = __builtin_amdgcn_udot4(arow[j], arow[j], bb, false);
+            bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
+            ab = __builtin_amdgcn_udot4(arow[j], b[j], ab, false);
+        }
+        asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
+    }
+    part = group8_sum(part);
+    part += (unsigned)__builtin_amdgcn_update_dpp(0, (int)part, 0x128, 0xF, 0xF, false);     // row_ror 8: the other half of the row
+    return part;
+}
+
+// minimum of one key per 16-lane row (every lane of a row holds its row's key) -> wave-uniform
+__device__ __forceinline__ unsigned rows_min(unsigned key)
+{
+    key = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key, 0x142, 0xA, 0xF, false));   // row_bcast15
+    key = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)INF32, (int)key, 0x143, 0xC, 0xF, false));   // row_bcast31
+    return (unsigned)__builtin_amdgcn_readlane((int)key, 63);
+}
+
 // minimum of one key per 8-lane group (every lane of a group holds its group's key) -> wave-uniform: one DPP rotate
 // inside each 16-lane row, rows 1,3 take lane 15 of the row below (row_bcast15), rows 2,3 take lane 31 (row_bcast31),
 // lane 63 ends with the minimum
@@ -320,9 +362,9 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     // anchors through a buffer resource as well: 32-bit offsets instead of 64-bit pointer arithmetic per lane
     const __amdgpu_buffer_rsrc_t ra = plane_rsrc(d.prev + (long long)pair * d.plane_stride, d.H * d.pitch);
-    const int aoff = __mul24(r0 + (lane & 7) * 2, d.pitch) + c0;
+    const int aoff = __mul24(r0 + (lane & 7), d.pitch) + c0;                    // block rows s and s + 8 (see walk_block)
     const u32x4_t t0 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff, 0, 0);
-    const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + d.pitch, 0, 0);
+    const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + 8 * d.pitch, 0, 0);
     f.a0 = make_uint4(t0.x, t0.y, t0.z, t0.w); f.a1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
     f.mine = __builtin_amdgcn_raw_buffer_load_b32(ra, __mul24(r0 + (lane >> 2), d.pitch) + c0 + 4 * (lane & 3), 0, 0);
     if (DIA) {
@@ -343,7 +385,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     const long long gid = (long long)pair * nblk + blk;
     const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     const int lane = threadIdx.x & 63;
-    const int grp = lane >> 3, lrow = (lane & 7) * 2;           // group = candidate slot, lane = 2 block rows
+    const int grp = lane >> 3, lrow = lane & 7;                 // group = candidate slot, lane = block rows lrow and lrow + 8
     const int H = d.H, W = d.W, pitch = d.pitch;
     const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
 
@@ -501,14 +543,20 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         {   // small pattern around the final centre
             RESTAGE_IF_OUTSIDE();
             int br = pr, bc = pc;
-            // offsets worked out here, once per block, rather than kept in two registers through the rounds (the
-            // volatile asm pins the computation to this place: 64 VGPRs are what 8 waves per SIMD allow)
-            int g4 = 4 * (grp & 3);
-            asm volatile("" : "+v"(g4));
-            const int my_sr = (int)((0x0121u >> g4) & 15u) - 1, my_sc = (int)((0x1012u >> g4) & 15u) - 1;
+            // One candidate per 16-lane row, one block row per lane (row16_eval_at).  Offsets worked out here, once per
+            // block, rather than kept in registers through the rounds (the volatile asm pins the computation to this
+            // place: 64 VGPRs are what 8 waves per SIMD allow); the anchors of the large rounds are not needed any more,
+            // so the lane's row overwrites a[0..3].
+            int c4 = 4 * (lane >> 4);
+            asm volatile("" : "+v"(c4));
+            const int my_sr = (int)((0x0121u >> c4) & 15u) - 1, my_sc = (int)((0x1012u >> c4) & 15u) - 1;
             const int rrv = clamp_med3(pr + my_sr, maxr), ccv = clamp_med3(pc + my_sc, maxc);
-            unsigned kmin;
-            PATTERN_MIN(4, window_offset(sbase, rrv, ccv, lrow52), (uint32_t)ccv & 3u, kmin);
+            uint32_t arow[4];
+            const uint32_t upper = 0u - (((uint32_t)lane >> 3) & 1u);          // all ones in lanes 8..15 of a row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) arow[j] = (a[4 + j] & upper) | (a[j] & ~upper);     // v_bfi_b32 (a select between array elements became an indexed scratch access)
+            const unsigned c_ = row16_eval_at<PNORM>(arow, window_offset(sbase, rrv, ccv, (lane & 15) * (4 * WIN_PITCH)), (uint32_t)ccv & 3u);
+            const unsigned kmin = rows_min((c_ << 3) | (unsigned)(lane >> 4));
             if ((kmin >> 3) < centre_cost) {
                 const unsigned k = kmin & 3u;
                 br = clamp_ref(pr + (int)((0x0121u >> (4 * k)) & 15u) - 1, maxr);
