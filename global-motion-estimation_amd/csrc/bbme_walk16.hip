@@ -5,7 +5,7 @@
 //                     next block's anchors and first window are fetched while the current one is walked, two
 //                     register sets used in turn).  The wave is cut into 8 groups
 //                     of 8 lanes; a group evaluates one candidate per round, each lane owning
-//                     two 16-byte rows of the block (ten dwords of the per-wave LDS window of
+//                     two 16-byte rows of the block, s and s + 8 (ten dwords of the per-wave LDS window of
 //                     `cur`, 8 v_alignbyte_b32, 8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8
 //                     anchor dwords kept in VGPRs), followed by a 3-step DPP reduction inside
 //                     the group.  Up to 8 candidates cost one round; the centre of a pattern is
@@ -106,7 +106,7 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
 }
 
 // Search-window cache: WIN_ROWS x WIN_DW dwords of `cur` per wave in LDS (row pitch WIN_PITCH is
-// odd, so the 8 lanes of a group -- 2 rows apart -- hit 8 different banks).  A candidate block
+// odd, so the 8 lanes of a group -- on 8 consecutive rows, in each of their two reads -- hit 8 different banks).  A candidate block
 // (rr, cc) can be served from it when 0 <= rr - wr0 <= WIN_ROWS - 16 and 0 <= cc - wc0 <= WIN_SPAN.
 constexpr int WIN_ROWS = 40, WIN_DW = 12, WIN_PITCH = 13, WIN_SPAN = 4 * (WIN_DW - 5) + 3;
 constexpr int WIN_ALLOC = 43 * WIN_PITCH;      // staging moves 128 sixteen-byte segments (2 per lane, no idle lanes): 42 2/3 rows

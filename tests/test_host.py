@@ -360,6 +360,23 @@ def test_committed_profiles_belong_to_these_kernels():
         assert os.path.exists(stats) and kernel.split("<")[0] in open(stats).read(), stats
 
 
+def test_pmc_summary_reads_only_the_newest_pass(tmp_path):
+    """tools/pmc_summary.py: gpurun merges a call's files INTO the local gpurun_out/, so a pass directory re-used by a later
+    profile run also holds the CSVs of earlier builds.  Only the newest CSV of each pass directory may enter the summary
+    (round 3: three runs had been averaged into one file under one kernel_source_sha)."""
+    import subprocess
+    d = tmp_path / "cfg" / "pmc_FETCH_SIZE" / "box"
+    d.mkdir(parents=True)
+    head = "Kernel_Name,Counter_Name,Counter_Value,Grid_Size,Workgroup_Size,LDS_Block_Size,VGPR_Count,SGPR_Count\n"
+    (d / "100_counter_collection.csv").write_text(head + "k_old(int),FETCH_SIZE,111,64,64,0,8,16\n")
+    os.utime(str(d / "100_counter_collection.csv"), (1000, 1000))
+    (d / "090_counter_collection.csv").write_text(head + "k_new(int),FETCH_SIZE,222,64,64,0,8,16\n" + "k_new(int),FETCH_SIZE,224,64,64,0,8,16\n")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summary.py"), str(tmp_path / "cfg"), "k_"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "k_new" in out and "mean=223" in out and "k_old" not in out, out
+    assert "# kernel_source_sha: " in out
+
+
 def test_stream_schedule_covers_every_pair_once():
     """StreamEstimator.schedule: chunks no larger than a lane holds, shrinking towards the end (the last chunk's estimate is
     the stretch no upload hides), never below min_chunk except for the remainder, every pair exactly once."""
