@@ -399,7 +399,8 @@ def measure(opt, ctx, comm, rank, world):
     # The ranges are driven by ONE host thread through the split-phase calls (ShardedSequence(interleave=True)):
     # gme720 1 stream 499-513 k pairs/s; 2 / 3 / 4 interleaved streams 582 / 588 / 596 k; with a host thread per
     # stream (GME_BENCH_INTERLEAVE=0) 2 / 3 / 4 streams gave 452-471 / 499 / 385-407 k on the same boxes.
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "3"))
+    # Round 3, final kernels, same box, four rounds: 2 / 3 / 4 / 6 ranges 619 / 647 / 655 / 634 k (means) -> 4.
+    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "4"))
     interleave = os.environ.get("GME_BENCH_INTERLEAVE", "1") == "1"      # one host thread over all streams (split-phase calls)
     shard = seq = None
     if proc == -3:
