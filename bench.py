@@ -74,8 +74,8 @@ ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080
                      "dia720mse": 0.01, "tss720": 0.01, "tdl720": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15,
                      "gme1080exh": 2.1}
 # the default line's "secondary" block: (config, pairs per step, steps, warmup, seconds of C-oracle parity)
-SECONDARY = [("gme720", 2048, 20, 3, 2.0), ("exh720mse", 2048, 8, 2, 2.0), ("dia720mse", 2048, 8, 2, 1.0),
-             ("tss720", 2048, 8, 2, 1.0), ("tdl720", 2048, 8, 2, 1.0),
+SECONDARY = [("gme720", 2048, 20, 3, 2.0), ("exh720mse", 2048, 12, 3, 2.0), ("dia720mse", 2048, 20, 3, 1.0),
+             ("tss720", 2048, 20, 3, 1.0), ("tdl720", 2048, 20, 3, 1.0),
              ("exh1080mse", 512, 3, 1, 6.0), ("gme1080exh", 512, 3, 1, 7.0)]
 
 
