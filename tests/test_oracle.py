@@ -411,3 +411,53 @@ def test_oracle_unmasked_fit(golden):
         gt = co.bbme(p, c, 16, 2, 3, 1)
         F, Sx, Sy = o.normal_sums(gt, np.zeros(gt.shape[:2], bool), p.shape)
         np.testing.assert_allclose(o.solve_parameters(F, Sx, Sy), g["bap_" + tag], rtol=1e-10, atol=1e-12, err_msg=tag)
+
+
+def test_c_and_numpy_oracles_agree_on_random_frames():
+    """The two restatements against each other where no golden reaches: random small frames (sizes that are no
+    multiples of the block size, pans, noise, flat areas with ties), every search, both norms, block sizes 2-16, windows
+    0-6 -- the C port (the checker of every GPU test) and the NumPy port (the line-by-line restatement) must agree
+    bit for bit; so must the rest of the GME chain on a random pair."""
+    co, o = c_oracle(), np_oracle()
+    rng = np.random.default_rng(20261004)
+    n = 0
+    for case in range(60):
+        H, W = int(rng.integers(17, 56)), int(rng.integers(17, 72))
+        kind = case % 4
+        if kind == 0:
+            base = rng.integers(0, 256, (H + 12, W + 12), dtype=np.uint8)
+            dy, dx = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+            p, c = base[6:6 + H, 6:6 + W], base[6 + dy:6 + dy + H, 6 + dx:6 + dx + W]
+        elif kind == 1:
+            p, c = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+        elif kind == 2:
+            p = np.full((H, W), 90, np.uint8)
+            c = p.copy()
+            c[H // 3:H // 2, W // 4:W // 2] = rng.integers(0, 256, (H // 2 - H // 3, W // 2 - W // 4), dtype=np.uint8)
+        else:
+            p = (rng.integers(0, 3, (H, W)) * 100).astype(np.uint8)
+            c = np.roll(p, (1, -2), axis=(0, 1))
+        p, c = np.ascontiguousarray(p), np.ascontiguousarray(c)
+        bs = int(rng.choice([2, 4, 8, 16]))
+        sw = int(rng.integers(0, 7))
+        for proc in range(4):
+            if proc == 3 and (H < bs + 1 or W < bs + 1):
+                continue
+            for pn in (0, 1):
+                got = co.bbme(p, c, bs, sw, proc, pn)
+                want = o.get_motion_field(p, c, block_size=bs, search_window=sw, searching_procedure=proc, pnorm_distance=pn)
+                assert np.array_equal(got, want), (case, H, W, bs, sw, proc, pn)
+                n += 1
+    assert n >= 400
+    for case in range(4):
+        H, W = int(rng.integers(70, 110)), int(rng.integers(70, 130))
+        base = rng.integers(0, 256, (H + 8, W + 8), dtype=np.uint8)
+        p, c = np.ascontiguousarray(base[4:4 + H, 4:4 + W]), np.ascontiguousarray(base[3:3 + H, 5:5 + W])
+        assert np.array_equal(co.pyrdown(p), o.pyr_down(p))
+        want = o.global_motion_estimation(p, c)
+        from helpers import oracle_gme
+        got, _ = oracle_gme(p, c)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+        field = co.affine_field(got, H // 16, W // 16)
+        assert np.array_equal(field, o.affine_field((H // 16, W // 16), got))
+        assert np.array_equal(co.compensate(p, field.astype(np.int32)), o.compensate_frame(p, field))
