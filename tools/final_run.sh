@@ -2,6 +2,8 @@
 #   bash tools/final_run.sh <tag> tests      GPU tests, the default bench line (with secondary block, sweeps, CPU baseline), rehearsals, scale_run
 #   bash tools/final_run.sh <tag> benches    one bench line per config (CPU baseline included) + hostile / real content lines
 #   bash tools/final_run.sh <tag> prof "<config:kernel-substring> ..."     tools/profile_configs.sh (bench + rocprofv3 kernel stats + PMC passes)
+#       round 3: "exh720:k_ exh720mse:k_ gme720:k_ tss720:k_ tdl720:k_ dia720mse:k_ exh1080:k_ exh1080mse:k_ gme1080exh:k_" (12.5 GPU-minutes)
+#       and "seq1080:k_ gme1080:k_ dia720:k_" (2.6); tests/test_host.py checks that all twelve belong to the committed kernels
 # Copy gpurun_out/<tag>/*_{bench.json,kernel_stats.csv,pmc_summary.txt} into profiles/ afterwards (tools/collect_profiles.sh).
 TAG=${1:-r03_final}; PART=${2:-tests}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
