@@ -649,6 +649,7 @@ def measure(opt, ctx, comm, rank, world):
     if info.get("patches"):
         out["elimination"] = {"patches": info["patches"], "surviving": info["surviving"],
                               "surviving_fraction": info["surviving"] / info["patches"],
+                              "listed_fraction_before_ordered_rounds": info["listed"] / info["patches"],
                               "tiles_redone_by_brute_force": info["redo_tiles"]}
 
     # ---- HBM traffic and issue statistics of the dominant kernel from the committed rocprofv3 PMC passes of
@@ -721,6 +722,7 @@ def measure(opt, ctx, comm, rank, world):
                 sweep[kind] = {"frame": "%dx%d" % (w2, h2), "content": CONTENT_NOTE[kind], "pairs": nsw,
                                "pairs_per_s": nsw / (ms * 1e-3), "kernel": inf["plan"].split(" grid")[0],
                                "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
+                               "listed_fraction_before_ordered_rounds": inf["listed"] / inf["patches"] if inf["patches"] else None,
                                "tiles_redone_by_brute_force": inf["redo_tiles"],
                                "parity_ok_sampled": bool(ok)}
                 s2.close()

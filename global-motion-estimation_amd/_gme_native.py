@@ -44,7 +44,9 @@ _SIGNATURES = {
     "gme_sync": (_i, [_vp]),
     "gme_stream": (_vp, [_vp]),
     "gme_device_info": (_i, [_vp, ctypes.c_char_p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "gme_device_bus_id": (_i, [_vp, ctypes.c_char_p, _i]),
     "gme_last_bbme_info": (_i, [_vp, ctypes.c_char_p, _i, _c_i64p, _c_i64p, _c_i64p]),
+    "gme_last_bbme_listed": (_i, [_vp, _c_i64p]),
     "gme_timer_start": (_i, [_vp]),
     "gme_timer_stop": (_i, [_vp, _c_f32p]),
     "gme_bbme_u8": (_i, [_vp, _c_u8p, _c_u8p, _i, _i, _i, _i, _i, _i, _i, _c_i32p]),
@@ -225,12 +227,14 @@ class Context:
 
     def last_bbme_info(self):
         """{'plan': kernel / tile shape / schedule of the last block-matching call,
-        'patches': candidate patches its elimination bound saw, 'surviving': those left for exact evaluation,
+        'patches': candidate patches its elimination bound saw, 'surviving': those scored exactly,
+        'listed': those each block's first upper bound left (what a single evaluation round would have scored),
         'redo_tiles': tiles handed to the brute-force redo kernel}."""
         plan = ctypes.create_string_buffer(192)
-        n, k, r = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        n, k, r, l = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         _check(self.lib.gme_last_bbme_info(self.handle, plan, 192, ctypes.byref(n), ctypes.byref(k), ctypes.byref(r)), self.lib)
-        return {"plan": plan.value.decode(), "patches": n.value, "surviving": k.value, "redo_tiles": r.value}
+        _check(self.lib.gme_last_bbme_listed(self.handle, ctypes.byref(l)), self.lib)
+        return {"plan": plan.value.decode(), "patches": n.value, "surviving": k.value, "listed": l.value, "redo_tiles": r.value}
 
     def timer_start(self):
         _check(self.lib.gme_timer_start(self.handle), self.lib)

@@ -75,6 +75,87 @@ __device__ __forceinline__ void lower_bounds(const uint64_t* sp0, int XQ, int pr
     }
 }
 
+// E, four lanes per patch: lane `sub` of a quad takes anchor rows 4*sub .. 4*sub+3 of the patch's block (R+3 window rows,
+// 16*R QSADs); the four partial u16x4 sums are added inside the quad with DPP moves, then lane `sub` turns column `sub`
+// of the patch into keys (sad << 13 | scan index).  Returns the quad's smallest key (0xFFFFFFFF: none).  Every lane of
+// the wave must call it (DPP); a quad is uniform in `ent` and `active`.
+// ent = wave << 25 | lane << 19 | k << 16 | bound: the patch of phase B's lane (prow, q), column group k, of block `wave`.
+template <int R>
+__device__ __forceinline__ uint32_t eval_patch_quad(const SeaDev& d, const uint32_t* win, const uint32_t* anchor, uint32_t ent,
+                                                    bool active, int sub, int trow, int bcol0, int NC)
+{
+    const int w2 = ent >> 25, l2 = (ent >> 19) & 63, k2 = (ent >> 16) & 7;
+    const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;     // the patch's block inside the tile
+    const int prow2 = l2 >> 2, q2 = l2 & 3;
+    uint64_t acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0;
+    if (active) {
+        const uint32_t* lrow = win + (16 * wr2 + prow2 * R + 4 * sub) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
+        const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + 16 * sub;
+#pragma unroll
+        for (int t = 0; t < R + 3; ++t) {
+            uint64_t w[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w[s] = *(const u64_a4*)(lrow + t * d.pitch_dw + s);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int a = t - i;                   // anchor row 4*sub + a
+                if (a < 0 || a > 3) continue;
+                const u32x4 ar = *(const u32x4*)(an + a * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(w[j], ar[j], acc[i]);
+            }
+        }
+    }
+    // sum over the quad: plain 32-bit adds on the packed u16 pairs (a 16x16 SAD is at most 65280, so no partial
+    // sum carries into the upper half) -- they take the DPP operand directly, v_pk_add_u16 needs a move first
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+        lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false);            // quad_perm [1,0,3,2]
+        hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+        lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false);            // quad_perm [2,3,0,1]
+        hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+        acc[i] = ((uint64_t)hi << 32) | lo;
+    }
+    uint32_t key = 0xFFFFFFFFu;
+    if (active) {
+        // every lane of the quad holds the patch's R x 4 sums now; lane `sub` turns column `sub` into keys
+        // (R candidates instead of 4 R on one lane)
+        const int c02 = (bcol0 + wc2) * 16, r02 = (trow * d.tr + wr2) * 16;
+        const int lo_c = max(0, d.sw - c02), hi_c = min(NC - 1, d.W - 16 - c02 + d.sw);
+        const int lo_r2 = max(0, d.sw - r02), hi_r2 = min(NC - 1, d.H - 16 - r02 + d.sw);
+        const bool rows_inside2 = NC == 16 * R && lo_r2 == 0 && hi_r2 == NC - 1;
+        const int ci = q2 * 4 * R + 4 * k2 + sub, ri0 = prow2 * R;
+        const uint32_t shift = (uint32_t)(sub & 1) * 16u;
+        if (rows_inside2 && lo_c == 0 && hi_c == NC - 1) {
+            // whole window inside the frame: keys relative to the column's first candidate, base added once
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const uint32_t word = (sub & 2) ? (uint32_t)(acc[i] >> 32) : (uint32_t)acc[i];
+                const uint32_t sad = __builtin_amdgcn_ubfe(word, shift, 16u);
+                key = min(key, (sad << 13) + (uint32_t)i);
+            }
+            key += (uint32_t)(ci * NC + ri0);
+        } else if (ci >= lo_c && ci <= hi_c) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int ri = ri0 + i;
+                if (ri < lo_r2 || ri > hi_r2) continue;
+                const uint32_t word = (sub & 2) ? (uint32_t)(acc[i] >> 32) : (uint32_t)acc[i];
+                const uint32_t sad = __builtin_amdgcn_ubfe(word, shift, 16u);
+                key = min(key, (sad << 13) | (uint32_t)(ci * NC + ri));
+            }
+        }
+        // quad minimum (a disabled source lane would hand back `key` itself; quads are uniform in `active`)
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    }
+    return key;
+}
+
 // Phases A' .. F of one tile.  On entry the window and the anchors are staged, *count == 0 and the
 // workgroup has passed a barrier; there is no barrier after F.
 // Returns true (workgroup-uniform) when the tile was handed to the redo kernel instead (SeaDev::redo_list).
@@ -135,6 +216,7 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
             pkd[k] = (pkey[k] & 0xFFFFE000u) | (first_idx + (uint32_t)(4 * k * NC));
             lb_key = min(lb_key, pkey[k]);
         }
+        const uint32_t lane_lb = lb_key;                               // this lane's smallest bound << 13 (| local index)
         if (lb_key != 0xFFFFFFFFu) lb_key += (uint32_t)lane << 7;      // local < 4R*R <= 100 < 128
         // ---- C: upper bound from two real candidates (cooperative 16x16 SAD, one dword per lane)
         lb_key = wave_min_u32(lb_key);
@@ -173,6 +255,57 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
             }
 #endif
         }
+        // ---- C2 (round 4): ordered evaluation inside a crowded block.  Where the first upper bound leaves more than
+        // SeaDev::quota patches (real content: the smallest bound does not name the best candidate, but the best one sits
+        // among the small bounds, tools/ub_study.py), the wave scores the up to 16 patches with the smallest bounds itself,
+        // four lanes each, before anything is listed: no barrier, a full wave, and phase D then tests the rest against
+        // (almost) the block's true minimum.  Any upper bound that is a real candidate's key keeps the result exact
+        // (bbme.py:171: only a smaller key replaces the best one).
+        uint32_t own_lim = 0;                              // keys below it were scored here (wave-uniform)
+        int n_w = 0;                                       // patches the first upper bound leaves (statistics)
+#ifndef SEA_NO_C2
+        if constexpr (E4) {
+            // crowded?  Lanes with a surviving patch are counted first (one ballot); the exact count only where it matters
+            if (d.quota > 0 && __popcll(__ballot((lane_lb & 0xFFFFE000u) < ub_key)) > d.engage / 3) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) n_w += __popcll(__ballot(pkd[k] < ub_key));
+                if (n_w > d.engage) {
+                    own_lim = first_round_limit(d, lb_key >> 13, ub_key >> 13, 13, [&](uint32_t lim) {
+                        int c = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) c += __popcll(__ballot(pkd[k] < lim));
+                        return c;
+                    });
+                    own_lim = min(own_lim, ub_key);
+                    // the chosen patches -> this wave's 16 slots (ties at the smallest bound may exceed them: the surplus
+                    // keeps own_rank >= 16 and is listed by phase D like everything else)
+                    uint32_t* own = lds + L.own + 16 * wave;
+                    int base_rank = 0;
+                    uint32_t listed_here = 0;              // bit k: patch k of this lane was scored here
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const bool sel = pkd[k] < own_lim;
+                        const unsigned long long m = __ballot(sel);
+                        const int rank = base_rank + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (sel && rank < 16) {
+                            own[rank] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | (pkd[k] >> 13);
+                            listed_here |= 1u << k;
+                        }
+                        base_rank += __popcll(m);
+                    }
+                    const int n_own = min(base_rank, 16);
+                    const bool act = (lane >> 2) < n_own;
+                    const uint32_t ent = act ? own[lane >> 2] : 0u;
+                    uint32_t key = eval_patch_quad<R>(d, win, anchor, ent, act, lane & 3, trow, bcol0, NC);
+                    ub_key = min(ub_key, wave_min_u32(key));
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+                        if (listed_here & (1u << k)) pkd[k] = 0xFFFFFFFFu;       // done: never listed
+                    if (lane == 0) atomicAdd(count + 5, (uint32_t)n_own);      // statistics
+                }
+            }
+        }
+#endif
         if (lane == 0) best[2 * wave] = ub_key;
         // ---- D: surviving patches -> workgroup list.  A candidate replaces the best one only with a smaller
         // key (sad << 13 | scan index: bbme.py:171 keeps the FIRST strict minimum), and its key is at least
@@ -185,6 +318,12 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
                 const uint32_t slot = atomicAdd(count, 1u);
                 work[slot] = ((uint32_t)wave << 25) | ((uint32_t)lane << 19) | ((uint32_t)k << 16) | (pkd[k] >> 13);   // LB <= 65280
             }
+        if (own_lim) {                                     // statistics: what the first bound had left and C2 took or pruned
+            int pushed = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) pushed += __popcll(__ballot(pkd[k] < ub_key));
+            if (lane == 0) atomicAdd(count + 4, (uint32_t)(n_w - pushed));
+        }
     }
     STAMP(5);
     __syncthreads();
@@ -199,8 +338,27 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
 #if defined(SEA_ABLATE) && SEA_ABLATE >= 1
     return false;                                          // timing-only build: + bounds, UB, list (no evaluation, no result)
 #endif
+#ifdef SEA_E_CALLS_EVAL
     if constexpr (E4) {
-        // ---- E (variant): four lanes per patch ---------------------------------------------------
+        // ---- E (variant): four lanes per patch (eval_patch_quad) -----------------------------------
+        const int n = (int)*count;
+        const int sub = lane & 3;
+        for (int base = 0; base < n; base += T / 4) {
+            const int e = base + (tid >> 2);
+            bool active = e < n;
+            uint32_t ent = 0;
+            if (active) ent = work[e];
+            // dropped by a tightened UB (same key rule as phase D); the quad is uniform in `active` (same entry)
+            active = active && (((ent & 0xFFFFu) << 13) | (uint32_t)(((int)((ent >> 19) & 3) * 4 * R + 4 * (int)((ent >> 16) & 7)) * NC + (int)((ent >> 21) & 15) * R)) < best[2 * (ent >> 25)];
+            const uint32_t key = eval_patch_quad<R>(d, win, anchor, ent, active, sub, trow, bcol0, NC);
+            if (active && sub == 0 && key != 0xFFFFFFFFu) atomicMin(&best[2 * (ent >> 25)], key);
+            __syncthreads();
+        }
+
+#else
+    if constexpr (E4) {
+        // ---- E (variant): four lanes per patch (the body of eval_patch_quad, kept inline here: the
+        // shared function cost this loop 1.2 % in register allocation, same-box A/B round 4) ---------------------------------------------------
         // Lane `sub` of a quad takes anchor rows 4*sub .. 4*sub+3 (R+3 window rows, 16*R QSADs); the four
         // partial u16x4 sums are added inside the quad with DPP moves.
         const int n = (int)*count;
@@ -286,6 +444,7 @@ __device__ __forceinline__ bool tile_phases(const SeaDev& d, uint32_t* lds, cons
             __syncthreads();
         }
 
+#endif
     } else {
         // ---- E: evaluate the listed patches, one per lane ---------------------------------------
         const int n = (int)*count;
@@ -416,12 +575,15 @@ __global__ void __launch_bounds__(1024) k_exh_sea16(SeaDev d)
     }
     const typename MaeTile<R, E4>::Pre pre = MaeTile<R, E4>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (lane == 0) lds[L.best + 2 * wave + 1] = (uint32_t)(d.sw * (2 * d.sw + 16) + d.sw);      // no previous tile: the zero vector
-    if (threadIdx.x == 0) lds[L.count] = 0;
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; }
     STAMP(1);
     __syncthreads();
     STAMP(2);
     MaeTile<R, E4>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
-    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
+    if (threadIdx.x == 0) {                                // the counts are final behind phase D's barrier
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count] + lds[L.count + 5]);
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7) + 2, lds[L.count] + lds[L.count + 4]);
+    }
 }
 
 template <int R, int NV, int GEO = 0>
@@ -470,13 +632,18 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     // hostile tiles (bound prunes little) -> brute-force redo kernel behind this one; GME_SEA_REDO=0 switches it off,
     // GME_SEA_REDO_FRAC sets the share of a tile's patches from which phase E costs more than evaluating everything
     d.redo_list = nullptr; d.redo_threshold = 0x7FFFFFFF;
+    // ordered evaluation inside crowded blocks (phase C2; bbme_sea_common.h: SeaDev::quota); GME_SEA_QUOTA=0 switches it off
+    d.quota = getenv("GME_SEA_QUOTA") ? atoi(getenv("GME_SEA_QUOTA")) : SEA_DEFAULT_QUOTA;
+    d.bisect = getenv("GME_SEA_BISECT") ? atoi(getenv("GME_SEA_BISECT")) : SEA_DEFAULT_BISECT;
+    d.engage = getenv("GME_SEA_ENGAGE") ? atoi(getenv("GME_SEA_ENGAGE")) : SEA_DEFAULT_ENGAGE;
+    if (d.engage < d.quota) d.engage = d.quota;
     const bool redo = !(getenv("GME_SEA_REDO") && atoi(getenv("GME_SEA_REDO")) == 0);
     if (redo) {
         int rc = ctx_redo_list(ctx, (size_t)job.pairs * d.wg_per_pair, &d.redo_list);
         if (rc) return rc;
         const double frac = getenv("GME_SEA_REDO_FRAC") ? atof(getenv("GME_SEA_REDO_FRAC")) : REDO_DEFAULT_FRAC;
         d.redo_threshold = (int)(frac * d.nb * 64 * R);
-        GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
+        if (!job.status_fresh) GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
     }
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
@@ -487,7 +654,7 @@ int launch_bbme_sea(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         const dim3 grid((unsigned)(8 * pp.g));
         if (pp.dynamic) {
             d.dynamic = 1;
-            GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+            if (!job.status_fresh) GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
         // the two BASELINE shapes (720x480 sw 16: 2x4 tiles; 1080p sw 32: 2x6 tiles) have instances with the tile
         // geometry folded in at compile time; GME_SEA_GENERIC=1 keeps the run-time form (A/B, tests)

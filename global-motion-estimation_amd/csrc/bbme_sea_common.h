@@ -32,8 +32,9 @@ struct SeaDev {
     unsigned long long magic_wpr; // same for n / wg_per_row
     uint32_t* status;             // the context's status words (gme_internal.h: GME_STATUS_*):
                                   //   + GME_STATUS_TILECTR  persistent kernel, dynamic schedule: one tile counter per XCD, 16 words apart
-                                  //   + GME_STATUS_STATS    per XCD, 16 words apart: [0] patches the bound left for exact evaluation
-                                  //                         (phase D's list), [1] tiles handed to the brute-force redo kernel
+                                  //   + GME_STATUS_STATS    per XCD, 16 words apart: [0] patches evaluated exactly (phase E), [1] tiles handed to
+                                  //                         the brute-force redo kernel, [2] patches phase D listed (what one
+                                  //                         round would have evaluated; == [0] without ordered evaluation)
                                   //   + GME_STATUS_REDO     [0] length of redo_list
     int dynamic;                  // persistent kernel: draw tiles from the per-XCD counters (else a static stride)
     // Hostile content (nothing correlates: a scene cut, noise): the bound prunes little and phase E's one-patch-
@@ -42,6 +43,13 @@ struct SeaDev {
     // (entry = tile number inside its XCD's tiles << 3 | xcd); the redo kernel launched behind this one searches it.
     uint32_t* redo_list;          // or null: no fallback
     int redo_threshold;
+    // Ordered evaluation (round 4, phase C2 of the kernels): a block whose first upper bound leaves more than `quota`
+    // patches scores those with the smallest bounds inside its own wave first (threshold by `bisect` halvings of [smallest
+    // bound, UB], at most `quota` <= 16 pass) and lists the rest against the upper bound that leaves.  On real content the
+    // smallest bound does not name the best candidate, but the best one sits among the small bounds: phase D then sees
+    // (almost) the block's true minimum (tools/ub_study.py).  quota <= 0: off.  `engage`: survivors from which a block
+    // counts as crowded (>= quota).
+    int quota, bisect, engage;
     int32_t* mf;
     int xq;                       // S8 quads (4 columns each) per window row
     const uint32_t* sqbox;        // MSE only: 16x16 box sums of squares of `cur`, [pairs][H][pitch]
@@ -109,7 +117,7 @@ constexpr int ANCHOR_STRIDE = 68;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Layout {
-    int win, anchor, best, count, a2, prev, s8, work, total;
+    int win, anchor, best, count, a2, prev, own, s8, work, total;
 };
 
 __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, int pitch_dw, int xq, int s8_rows)
@@ -118,11 +126,16 @@ __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, in
     l.win = 0;
     l.anchor = (win_rows * pitch_dw + 3) & ~3;         // 16-byte aligned: anchor rows are read as b128
     l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
-    l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [2] list lengths of earlier tiles,
-                                                       // [3] streak of hostile tiles (persistent_tiles)
-    l.a2 = l.count + 4;
+    l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [3] streak of hostile tiles (persistent_tiles),
+                                                       // [4] patches phase C2 took off the list (scored or pruned), [5] patches C2 scored
+    l.a2 = l.count + 8;
     l.prev = l.a2 + nb;                                // [nb] scan index each wave's block of the previous tile ended with (third probe)
-    l.s8 = (l.prev + nb + 1) & ~1;                     // 8-byte aligned, [s8_rows][xq] u16x4
+    l.own = l.prev + nb;                               // [nb][16] phase C2: the patches a crowded block's wave scores itself
+#ifdef SEA_NO_OWN
+    l.s8 = (l.own + 1) & ~1;
+#else
+    l.s8 = (l.own + 16 * nb + 1) & ~1;                 // 8-byte aligned, [s8_rows][xq] u16x4
+#endif
     l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
     l.total = l.work + nb * 64 * R;
     return l;
@@ -401,6 +414,7 @@ inline bool plan(int R, int nbr, int nbc, int sw, SeaDev* d, size_t* lds_bytes)
     return d->rstep >= 1;
 }
 
+constexpr int SEA_DEFAULT_QUOTA = 16, SEA_DEFAULT_BISECT = 5, SEA_DEFAULT_ENGAGE = 24;     // tools/ub_study.py; same-box A/B in DESIGN.md
 constexpr int REDO_BURST = 15;
 constexpr double REDO_DEFAULT_FRAC = 0.75;     // break-even measured on noise content
 
@@ -409,6 +423,21 @@ __device__ __forceinline__ void push_redo(const SeaDev& d, int tile_in_xcd, int 
     const uint32_t slot = atomicAdd(d.status + GME_STATUS_REDO, 1u);
     d.redo_list[slot] = ((uint32_t)tile_in_xcd << 3) | (uint32_t)xcd;
     atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd + 1, 1u);
+}
+
+// Phase C2's choice of a crowded block's first patches (wave-uniform): keys below the returned limit are scored first.
+// `below(lim)` counts the wave's patches whose key is below lim; lo / hi are the smallest bound and the UB (same unit,
+// `shift` = position of the bound inside a key).  Invariant: at most `quota` keys lie below (lo + 1) << shift, or lo is
+// the smallest bound itself (ties may exceed the quota: they all go first).
+template <class Below>
+__device__ __forceinline__ uint32_t first_round_limit(const SeaDev& d, uint32_t lo, uint32_t hi, int shift, Below below)
+{
+    if (d.bisect < 0) return (lo + ((hi - lo) >> -d.bisect) + 1) << shift;      // no search: the lowest 1 / 2^n of the range
+    for (int s = 0; s < d.bisect && lo < hi; ++s) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((int)below((mid + 1) << shift) > d.quota) hi = mid; else lo = mid;
+    }
+    return (lo + 1) << shift;
 }
 
 // tile number (inside its XCD's tiles) of the one-tile kernels' workgroup: what persistent_tiles calls `t`
@@ -480,7 +509,8 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
     uint32_t* ctr = d.dynamic ? d.status + GME_STATUS_TILECTR + 16 * xcd : nullptr;
     uint32_t drawn = 0;
     if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
-    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 2] = 0; lds[L.count + 3] = 0; }
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 3] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; }
+    uint32_t stat_scored = 0, stat_listed = 0;             // thread 0's: patches scored exactly / left by the first upper bounds
     for (;;) {
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -499,8 +529,13 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         const uint32_t mine = an_next;
         const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, wave_block(d, trow_c, bcol0_c, wave).ok, mine);
         if (tid == 0) {
-            lds[L.count + 2] += lds[L.count];              // the finished tile's list length (statistics)
-            lds[L.count] = 0;
+            // the finished tile's counts (final behind its phase D barrier) -> statistics, then cleared for this tile
+#ifndef SEA_NO_STATS
+            const uint32_t listed = lds[L.count], c2_off = lds[L.count + 4], c2_scored = lds[L.count + 5];
+            stat_scored += listed + c2_scored;
+            stat_listed += listed + c2_off;
+#endif
+            lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0;
             if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
         }
         __syncthreads();
@@ -536,10 +571,19 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         }
 #endif
         if (!more) break;
-        __syncthreads();                                   // everyone is done with this tile's LDS
+        // No barrier here (round 4): every wave has passed phase D's barrier, and phase E's chunks end in one each, so
+        // nobody still reads the window, the anchors, the box sums or the list when the next tile's staging overwrites them;
+        // what is touched between here and the next tile's first barrier is per wave (best[], prev[]) or thread 0's
+        // (the count words: a wave that has not read the list length yet can only be in a tile whose list is empty).
+#ifdef SEA_TILE_END_BARRIER
+        __syncthreads();
+#endif
     }
-    // thread 0 has passed the barrier behind phase D: the last tile's list length is final
-    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd, lds[L.count + 2] + lds[L.count]);
+    // thread 0 has passed the barrier behind phase D: the last tile's counts are final
+    if (threadIdx.x == 0) {
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd, stat_scored + lds[L.count] + lds[L.count + 5]);
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * xcd + 2, stat_listed + lds[L.count] + lds[L.count + 4]);
+    }
 }
 
 // Host side of the persistent form: resident workgroups per XCD (what LDS and the 32 wave slots of

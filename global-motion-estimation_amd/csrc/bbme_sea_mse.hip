@@ -325,10 +325,13 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     }
     const typename MseTile<R, LPPT>::Pre pre = MseTile<R, LPPT>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (lane == 0) lds[L.prev + wave] = (uint32_t)(d.sw * (2 * d.sw + 16) + d.sw);       // no previous tile: the zero vector
-    if (threadIdx.x == 0) lds[L.count] = 0;
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; }
     __syncthreads();
     MseTile<R, LPPT>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
-    if (threadIdx.x == 0) atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);     // list length is final behind phase D
+    if (threadIdx.x == 0) {                                // list length is final behind phase D
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7), lds[L.count]);
+        atomicAdd(d.status + GME_STATUS_STATS + 16 * (blockIdx.x & 7) + 2, lds[L.count]);
+    }
 }
 
 #ifndef SEA_MSE_LPP
@@ -371,13 +374,17 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
     // hostile tiles (bound prunes little) -> brute-force redo kernel behind this one; GME_SEA_REDO=0 switches it off,
     // GME_SEA_REDO_FRAC sets the share of a tile's patches from which phase E costs more than evaluating everything
     d.redo_list = nullptr; d.redo_threshold = 0x7FFFFFFF;
+    // No ordered evaluation (phase C2 of bbme_sea.hip) here: measured -6 % on every content (round 4): with one
+    // lane per patch a 720x480 tile's list is a single pass either way, and under MSE the quadrant bound is too weak for the
+    // tightened upper bound to prune much (pan240 x2: 30 -> 25 % of the patches).
+    d.quota = 0; d.bisect = 0; d.engage = 0;
     const bool redo = !(getenv("GME_SEA_REDO") && atoi(getenv("GME_SEA_REDO")) == 0);
     if (redo) {
         int rc = ctx_redo_list(ctx, (size_t)job.pairs * d.wg_per_pair, &d.redo_list);
         if (rc) return rc;
         const double frac = getenv("GME_SEA_REDO_FRAC") ? atof(getenv("GME_SEA_REDO_FRAC")) : REDO_DEFAULT_FRAC;
         d.redo_threshold = (int)(frac * d.nb * 64 * R);
-        GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
+        if (!job.status_fresh) GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_REDO, 0, 2 * sizeof(uint32_t), ctx->stream));
     }
     const PersistPlan pp = plan_persistent(d, lds, job.pairs, ctx->prop.multiProcessorCount);
     const int nv = pp.nv;
@@ -389,7 +396,7 @@ int launch_bbme_sea_mse(gme_ctx* ctx, const BbmeJob& job, bool* handled)
         const dim3 grid((unsigned)(8 * pp.g));
         if (pp.dynamic) {
             d.dynamic = 1;
-            GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
+            if (!job.status_fresh) GME_HIP_TRY(hipMemsetAsync(d.status + GME_STATUS_TILECTR, 0, 8 * 16 * sizeof(uint32_t), ctx->stream));
         }
         // the two BASELINE shapes (720x480 sw 16: 2x4 tiles; 1080p sw 32: 2x6 tiles) have instances with the tile
         // geometry folded in at compile time; GME_SEA_GENERIC=1 keeps the run-time form (A/B, tests)

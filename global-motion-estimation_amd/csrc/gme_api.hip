@@ -186,6 +186,18 @@ extern "C" int gme_last_bbme_info(gme_ctx* ctx, char* plan, int plan_len, int64_
     return GME_OK;
 }
 
+extern "C" int gme_last_bbme_listed(gme_ctx* ctx, int64_t* listed)
+{
+    GME_ENTER(ctx);
+    uint32_t st[8 * 16];
+    GME_HIP_TRY(hipMemcpyAsync(st, ctx->status + GME_STATUS_STATS, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    GME_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int64_t n = 0;
+    for (int x = 0; x < 8; ++x) n += st[16 * x + 2];
+    if (listed) *listed = n;
+    return GME_OK;
+}
+
 extern "C" void* gme_stream(gme_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" int gme_device_info(gme_ctx* ctx, char* name, int name_len, int* cu_count, int* clock_khz)
@@ -194,6 +206,16 @@ extern "C" int gme_device_info(gme_ctx* ctx, char* name, int name_len, int* cu_c
     if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
     if (clock_khz) *clock_khz = ctx->prop.clockRate;
+    return GME_OK;
+}
+
+extern "C" int gme_device_bus_id(gme_ctx* ctx, char* out, int out_len)
+{
+    GME_ENTER(ctx);
+    GME_REQUIRE(out != nullptr && out_len >= 16, GME_ERR_ARG, "gme_device_bus_id: buffer of at least 16 bytes");
+    GME_HIP_TRY(hipDeviceGetPCIBusId(out, out_len, ctx->device));
+    const hipError_t q = hipStreamQuery(ctx->stream);                  // the device still answers (work in flight is fine)
+    GME_REQUIRE(q == hipSuccess || q == hipErrorNotReady, GME_ERR_HIP, "gme_device_bus_id: %s", hipGetErrorString(q));
     return GME_OK;
 }
 

@@ -140,6 +140,7 @@ struct BbmeJob {
     const uint32_t* sqbox_cur;    // optional, matches `cur` planes: [pairs][H][pitch] uint32 (SqTable)
     int64_t sqbox_stride;         // elements between consecutive planes
     bool chained = false;         // a later chunk of one streamed call: keep the plan text and the statistics
+    bool status_fresh = false;    // launch_bbme has just cleared the tile counters and redo words (first chunk of a call)
 };
 int launch_bbme(gme_ctx* ctx, const BbmeJob& job);
 int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int tile_wg_per_row, int tile_wg_per_pair,

@@ -77,6 +77,14 @@ def _rendezvous_base():
     st = os.lstat(d)
     if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
         raise PermissionError("%s is not a private directory of uid %d (mode %o, owner %d)" % (d, os.getuid(), st.st_mode & 0o7777, st.st_uid))
+    try:                                         # day-old leftovers of earlier launches (ack files, crashed attempts)
+        for name in os.listdir(d):
+            path = os.path.join(d, name)
+            st1 = os.lstat(path)
+            if stat.S_ISREG(st1.st_mode) and st1.st_uid == os.getuid() and st1.st_mtime < time.time() - 86400:
+                os.unlink(path)
+    except OSError:
+        pass
     return os.path.join(d, "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
 
 
@@ -86,14 +94,23 @@ class Rendezvous:
     there.  A file is accepted only if it is a regular file of this user and not older than this process (minus a few
     minute of start-up skew): what an earlier launch with the same port and parent left behind is never read."""
 
+    _attempts = {}               # base -> rendezvous objects this process has made for it (ranks make them collectively)
+
     def __init__(self, rank, world, timeout_s=180.0, base=None):
         self.rank, self.world, self.timeout_s = int(rank), int(world), float(timeout_s)
         self.base = base or _rendezvous_base()
         self.not_before = _process_start_time() - _STALE_SLACK_S
         self._mine = []
+        # Attempt nonce (ADVICE r3): a second bring-up in the same processes, or a worker group restarted by the same
+        # torchrun agent (same port, same parent pid), must never read the first attempt's files -- a stale "no:" marker
+        # or, worse, a stale ncclUniqueId (ranks entering ncclCommInitRank with different ids hang for good).  Every
+        # rank of a launch makes its rendezvous objects in the same order, so the counter agrees across ranks.
+        n = Rendezvous._attempts.get(self.base, 0)
+        Rendezvous._attempts[self.base] = n + 1
+        self.attempt = "a%s_%d" % (os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), n)
 
     def _path(self, key, rank):
-        return "%s.%s.%d" % (self.base, key, rank)
+        return "%s.%s.%s.%d" % (self.base, self.attempt, key, rank)
 
     def publish(self, key, blob):
         path = self._path(key, self.rank)
@@ -143,8 +160,22 @@ class Rendezvous:
         blobs = self.collect(key)
         bad = ["rank %d: %s" % (r, b[3:].decode("utf-8", "replace")) for r, b in enumerate(blobs) if not b.startswith(b"ok:")]
         if bad:
-            raise CommUnavailable("%s failed on %d of %d ranks (%s)" % (key, len(bad), self.world, "; ".join(bad)))
+            self.fail(key, "%s failed on %d of %d ranks (%s)" % (key, len(bad), self.world, "; ".join(bad)))
         return [b[3:] for b in blobs]
+
+    def fail(self, key, message):
+        """Raise CommUnavailable(message) -- called with the same verdict on every rank.  One more round first says that
+        every rank has READ every file; then each rank removes its own.  The 4-byte ack files themselves stay (a rank
+        that is done may exit before the slowest rank has read its ack; the attempt nonce keeps a later bring-up away
+        from them, and _rendezvous_base sweeps day-old files out of the private directory)."""
+        try:
+            self.publish("ack_" + key, b"read")
+            self.collect("ack_" + key)
+            self._mine = [p for p in self._mine if ".ack_" not in os.path.basename(p)]
+            self.cleanup()
+        except TimeoutError:
+            pass
+        raise CommUnavailable(message)
 
     def cleanup(self):
         """Remove this rank's own files (call only once every rank is known to have read them)."""
@@ -174,22 +205,37 @@ def comm_exchange_id(make_id, rank, world, timeout_s=180.0, rdv=None):
     return blob
 
 
-def collective_init(rdv, probe, make_id, init, destroy):
+def collective_init(rdv, probe, make_id, init, destroy, device_tag=None):
     """The agreement around ncclCommInitRank, which cannot time out: (1) every rank loads RCCL (`probe`) and rank 0
     makes the id; all ranks learn whether all could, and nobody enters the collective otherwise; (2) every rank runs
     `init(id)`; all ranks learn whether all succeeded, and those that did `destroy()` their communicator
-    otherwise.  Either every rank returns, or every rank raises CommUnavailable."""
-    blob, err = b"", None
+    otherwise.  Either every rank returns, or every rank raises CommUnavailable -- PROVIDED every rank that passed
+    phase 1 really enters ncclCommInitRank in `init`: a rank whose `init` fails before the collective (device lost
+    between probe and init, out of memory) leaves its peers inside a call that cannot time out, and only the
+    launcher's own timeout ends the launch.  Everything that can fail locally therefore belongs in `probe`
+    (comm_init: gme_comm_probe loads RCCL AND binds the context's device; the payload carries the device's PCI bus id
+    and phase 1 refuses two ranks on one device, which RCCL would only refuse inside the collective)."""
+    blob, err, tag = b"", None, b""
     try:
         probe()
+        if device_tag is not None:
+            tag = device_tag()
         if rdv.rank == 0:
             blob = make_id()
     except Exception as e:                        # noqa: BLE001 -- reported to every rank below
         err = e
-    blobs = rdv.agree("probe", err is None, blob if err is None else repr(err).encode())
+    payload = len(tag).to_bytes(2, "little") + tag + blob
+    blobs = rdv.agree("probe", err is None, payload if err is None else repr(err).encode())
+    tags = [b[2:2 + int.from_bytes(b[:2], "little")] for b in blobs]
+    shared = sorted({t for t in tags if t and tags.count(t) > 1})
+    if shared and not os.environ.get("GME_COMM_ALLOW_SHARED_DEVICE"):
+        # every rank sees the same tags, so every rank raises -- before anybody is inside ncclCommInitRank
+        rdv.fail("probe", "probe: ranks share a device (%s): RCCL wants one device per rank" % ", ".join(
+            "%s on ranks %s" % (t.decode("utf-8", "replace"), [r for r, x in enumerate(tags) if x == t]) for t in shared))
+    uid = blobs[0][2 + len(tags[0]):]
     err = None
     try:
-        init(blobs[0])
+        init(uid)
     except Exception as e:                        # noqa: BLE001
         err = e
     try:
@@ -216,13 +262,18 @@ def comm_init(ctx, rank, world, timeout_s=180.0):
     def init(blob):
         _native._check(lib.gme_comm_init(ctx.handle, blob, rank, world), lib)
 
+    def device_tag():
+        buf = ctypes.create_string_buffer(64)
+        _native._check(lib.gme_device_bus_id(ctx.handle, buf, 64), lib)     # also binds the device: fails HERE, not in init
+        return buf.value
+
     if world == 1:
         probe()
         init(make_id())
         comm_barrier(ctx)
         return
     rdv = Rendezvous(rank, world, timeout_s)
-    collective_init(rdv, probe, make_id, init, lambda: comm_destroy(ctx))
+    collective_init(rdv, probe, make_id, init, lambda: comm_destroy(ctx), device_tag)
     comm_barrier(ctx)                            # every rank has read every file once this returns
     rdv.cleanup()
 

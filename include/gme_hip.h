@@ -64,6 +64,11 @@ GME_API gme_ctx *gme_create(int device_id);
 GME_API void gme_destroy(gme_ctx *ctx);
 GME_API int gme_sync(gme_ctx *ctx);
 GME_API int gme_device_info(gme_ctx *ctx, char *name, int name_len, int *cu_count, int *clock_khz);
+/* PCI bus id of the context's device ("0000:05:00.0"); makes that device current and checks that it answers.  The
+ * all-ranks-agree bring-up of the RCCL communicator (sequence.comm_init) publishes it in its first phase, so that a
+ * lost device or two ranks on one device end in a clean refusal on every rank instead of inside ncclCommInitRank.
+ * No reference counterpart (the reference is single-process, results.py:41-50). */
+GME_API int gme_device_bus_id(gme_ctx *ctx, char *out, int out_len);
 /* opaque handle of the context's HIP stream (hipStream_t), for callers that
  * want to order their own work or events after the library's */
 GME_API void *gme_stream(gme_ctx *ctx);
@@ -78,6 +83,11 @@ GME_API void *gme_stream(gme_ctx *ctx);
  * Any pointer may be NULL.  Synchronises. */
 GME_API int gme_last_bbme_info(gme_ctx *ctx, char *plan, int plan_len, int64_t *patches, int64_t *surviving,
                        int64_t *redo_tiles);
+/* Same call, one more figure: the patches the FIRST upper bound of each block left (what a single evaluation round
+ * would have scored); gme_last_bbme_info's `surviving` is what the ordered two-round evaluation really scored
+ * (the exactness argument of bbme.py:171 -- only a smaller key replaces the best one -- holds for any upper bound that
+ * is a real candidate's cost, so tightening it between the rounds changes the work, never the result).  Synchronises. */
+GME_API int gme_last_bbme_listed(gme_ctx *ctx, int64_t *listed);
 
 /* HIP-event stopwatch on the context's stream (bench.py: kernel time of the timed region) */
 GME_API int gme_timer_start(gme_ctx *ctx);

@@ -250,7 +250,7 @@ def test_rccl_id_rendezvous_and_padding(tmp_path):
     for r, p in zip((1, 2), late):
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0 and ("rank%d got the id" % r) in out
-    path = "/tmp/gme_rccl_%d/29777_%d.id.0" % (os.getuid(), os.getpid())       # a private directory, keyed by port and parent
+    path = "/tmp/gme_rccl_%d/29777_%d.a0_0.id.0" % (os.getuid(), os.getpid())  # a private directory, keyed by port, parent, attempt
     assert os.path.exists(path) and (os.stat(path).st_mode & 0o777) == 0o600
     assert (os.stat(os.path.dirname(path)).st_mode & 0o777) == 0o700
     os.unlink(path)
@@ -262,6 +262,7 @@ def test_rccl_id_rendezvous_and_padding(tmp_path):
         with pytest.raises(OSError):
             sequence.comm_exchange_id(broken, 0, 2)
         t0 = time.time()
+        sequence.Rendezvous._attempts.clear()              # "rank 1" is another process: its first attempt with this key
         with pytest.raises(RuntimeError):
             sequence.comm_exchange_id(broken, 1, 2, timeout_s=60)
         assert time.time() - t0 < 5
@@ -308,6 +309,58 @@ sys.stdout.write("rank%%d %%s comm=%%s entered_init=%%s\n" %% (rank, out, state[
 """
 
 
+_RETRY = r"""
+import os, sys
+sys.path[:0] = [%(pkg)r]
+import sequence
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+log = []
+for attempt in (0, 1, 2):
+    def probe():
+        if attempt == 0 and rank == 1:
+            raise OSError("cannot open librccl.so")
+    def make_id():
+        return bytes([attempt]) * 128
+    def init(blob):
+        assert blob == bytes([attempt]) * 128, "rank %%d read another attempt's id" %% rank
+    def tag():
+        return b"0000:05:00.0" if attempt == 1 else b"0000:%%02x:00.0" %% rank      # attempt 1: both ranks on one device
+    rdv = sequence.Rendezvous(rank, world, timeout_s=60)
+    try:
+        sequence.collective_init(rdv, probe, make_id, init, lambda: None, tag)
+        log.append("up")
+    except sequence.CommUnavailable as e:
+        log.append("unavailable[%%s]" %% e)
+    left = sorted(f for f in os.listdir(os.path.dirname(rdv.base)) if f.startswith(os.path.basename(rdv.base) + ".") and ".ack_" not in f
+                  and f.endswith(".%%d" %% rank))
+    log.append("left=%%d" %% len(left))
+sys.stdout.write("rank%%d %%s\n" %% (rank, " | ".join(log)))
+"""
+
+
+def test_comm_init_can_be_retried_with_the_same_key(tmp_path):
+    """a failed bring-up used to leave its probe.* / init.* files behind, keyed only by (port, parent pid): a
+    second comm_init in the same processes could read the first attempt's 'no:' marker or its ncclUniqueId.  Keys now
+    carry an attempt nonce and a failed attempt removes its files (after an ack round).  Three attempts with ONE base:
+    a probe failure, two ranks on one device (refused in phase 1, nobody enters init), then a good one whose id must be
+    its own."""
+    script = tmp_path / "retry.py"
+    script.write_text(_RETRY % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
+    env = dict(os.environ, GME_COMM_ID_FILE=str(tmp_path / "launch"))
+    env.pop("GME_COMM_ALLOW_SHARED_DEVICE", None)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (1, 0)]
+    for r, p in zip((1, 0), procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err
+        parts = out.strip().split(" | ")
+        assert parts[0].startswith("rank%d unavailable[probe failed on 1 of 2 ranks (rank 1: OSError" % r), out
+        assert parts[1] == "left=0", out                                  # the failed attempt removed its files
+        assert "ranks share a device (0000:05:00.0 on ranks [0, 1])" in parts[2] and parts[3] == "left=0", out
+        assert parts[4] == "up", out
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("launch.") and ".ack_" not in f and ".a0_2." not in f], os.listdir(tmp_path)
+
+
 @pytest.mark.parametrize("scenario", ["all_fine", "probe_fails_on_2", "init_fails_on_1"])
 def test_comm_init_is_decided_by_all_ranks(tmp_path, scenario):
     """VERDICT r2 / ADVICE: the transport is never chosen per rank.  sequence.collective_init wraps ncclCommInitRank in
@@ -317,7 +370,7 @@ def test_comm_init_is_decided_by_all_ranks(tmp_path, scenario):
     script = tmp_path / "agree.py"
     script.write_text(_AGREE % {"pkg": os.path.join(REPO, "global-motion-estimation_amd")})
     base = str(tmp_path / "launch")
-    stale = base + ".probe.0"                              # an earlier launch with the same key died after saying "no"
+    stale = base + ".a0_0.probe.0"                         # an earlier launch with the same key died after saying "no"
     with open(stale, "wb") as f:
         f.write(b"no:stale failure marker")
     os.utime(stale, (1.0e9, 1.0e9))
