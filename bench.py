@@ -62,7 +62,15 @@ CONFIGS = {
                 "diamond-search GME + compensate + PSNR, RCCL all-gather of per-pair parameters (BASELINE configs[4])"),
     "gme1080": (1080, 1920, 16, 2, -1, 1, 2000, "1920x1080 synthetic sequence, diamond-search GME + compensate, "
                 "BASELINE configs[4] per-GPU shard"),
+    # the block sizes the reference itself runs besides 16
+    "tss_bs4sw2": (480, 720, 4, 2, 1, 1, 1234, "720x480 synthetic luma, bs=4 sw=2 three-step search MSE: bbme.get_motion_field's own "
+                   "defaults (bbme.py:15-18)"),
+    "gme_pan240_bs12fd5": (240, 320, 12, 2, -1, 1, 0, "320x240 real frames (the reference's 51 pan240 frames, walked back and forth), full GME "
+                           "+ compensate + PSNR at the slides' setting BBME_BLOCK_SIZE=12, frame distance 5 "
+                           "(docs/presentation/main.tex:382; golden g9)"),
 }
+# per-config extras: frame content uploaded from the host instead of the synthetic generator, frame distance
+EXTRA = {"gme_pan240_bs12fd5": {"content": "pan240seq", "fd": 5}}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # measured on MI355X (tools/microbench/valu_rates2.hip, profiles/r01_valu_rates.txt):
 # v_qsad_pk_u16_u8 issues one wave-instruction (64 lanes x 16 byte-abs-diffs) per ~16.3
@@ -72,11 +80,14 @@ PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per b
 # rough C-oracle seconds per pair (one core), to size the parity sample
 ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080mse": 1.8, "dia720": 0.01,
                      "dia720mse": 0.01, "tss720": 0.01, "tdl720": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15,
-                     "gme1080exh": 2.1}
-# the default line's "secondary" block: (config, pairs per step, steps, warmup, seconds of C-oracle parity)
-SECONDARY = [("gme720", 2048, 20, 3, 2.0), ("exh720mse", 2048, 12, 3, 2.0), ("dia720mse", 2048, 20, 3, 1.0),
-             ("tss720", 2048, 20, 3, 1.0), ("tdl720", 2048, 20, 3, 1.0),
-             ("exh1080mse", 512, 3, 1, 6.0), ("gme1080exh", 512, 3, 1, 7.0)]
+                     "gme1080exh": 2.1, "tss_bs4sw2": 0.02, "gme_pan240_bs12fd5": 0.01}
+# the default line's "secondary" block: (config, pairs per step, steps, warmup, wall seconds of C-oracle parity on
+# ORACLE_THREADS threads, pairs the parity gate checks at least).  seq1080 = BASELINE configs[4] at N = 1: the whole
+# 2000-frame video, with the world-1 RCCL all-gather (gme_shard_gather) inside every step.
+SECONDARY = [("gme720", 2048, 20, 3, 1.0, 8), ("exh720mse", 2048, 12, 3, 1.0, 8), ("dia720mse", 2048, 20, 3, 0.5, 8),
+             ("tss720", 2048, 20, 3, 0.5, 8), ("tdl720", 2048, 20, 3, 0.5, 8),
+             ("tss_bs4sw2", 2048, 20, 3, 0.5, 8), ("gme_pan240_bs12fd5", 2048, 20, 3, 0.5, 8),
+             ("exh1080mse", 512, 8, 2, 3.0, 8), ("gme1080exh", 512, 8, 2, 3.5, 8), ("seq1080", None, 8, 2, 2.0, 8)]
 
 
 def algorithmic_bytes(H, W, bs, gme=False):
@@ -206,8 +217,21 @@ def sample_pairs(n_pairs, want):
     return sorted(set(int(round(x)) for x in np.linspace(0, n_pairs - 1, want)))
 
 
-def parity_sample_size(config, budget_s=PARITY_BUDGET_S):
-    return int(max(3, min(64, budget_s / ORACLE_S_PER_PAIR.get(config, 0.1))))
+ORACLE_THREADS = max(1, min(8, (os.cpu_count() or 2) - 1))     # the C oracle is re-entrant and ctypes releases the GIL
+
+
+def parity_sample_size(config, budget_s=PARITY_BUDGET_S, at_least=3):
+    """Pairs the parity gate checks: what `budget_s` seconds of wall clock buy with ORACLE_THREADS oracle threads."""
+    return int(max(at_least, min(64, budget_s * ORACLE_THREADS / ORACLE_S_PER_PAIR.get(config, 0.1))))
+
+
+def oracle_map(fn, items):
+    """fn over items on ORACLE_THREADS threads (the checker's own parallelism: nothing of the product path runs here)."""
+    if ORACLE_THREADS == 1 or len(items) < 2:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(ORACLE_THREADS) as ex:
+        return list(ex.map(fn, items))
 
 
 def cpu_baseline_exhaustive(cfg, budget_s=14.0):
@@ -297,6 +321,7 @@ class Comm:
     def __init__(self, ctx, rank, world, local):
         self.ctx, self.rank, self.world, self.kind, self.dist, self.torch = ctx, rank, world, "none", None, None
         self.rccl_reports = None
+        self.degraded = None                       # set when the agreed fallback transport carries the rows instead of the C ABI's RCCL
         if world == 1 and not os.environ.get("GME_BENCH_FORCE_DIST"):
             return
         backend = os.environ.get("GME_BENCH_BACKEND", "rccl")
@@ -320,6 +345,7 @@ class Comm:
                     print("bench.py rank %d: C-ABI RCCL communicator unavailable on this launch (%s); all ranks fall back to "
                           "torch.distributed" % (rank, e), file=sys.stderr)
                     backend = "nccl"
+                    self.degraded = "torch.distributed fallback (C-ABI RCCL communicator unavailable: %s)" % e
                 # anything else (a rendezvous timeout, a HIP error) is not agreed between the ranks: die non-zero
             self._torch_init(backend, rank, world, local)
         finally:
@@ -354,6 +380,9 @@ class Comm:
             if self.torch.cuda.is_available():
                 self.torch.cuda.synchronize()
 
+    def min(self, value):
+        return -self.max(-value)
+
     def max(self, value):
         if self.rccl:
             import sequence
@@ -383,6 +412,14 @@ class Comm:
         self.kind = "none"
 
 
+def rank_report(comm, rate_local, gather_s, steps):
+    """What an N > 1 line says about its ranks: the slowest and the fastest rank's own pairs/s (collective: every rank
+    calls it) and the host-timed cost of the step's exchange on this rank (None where the exchange is queued on the stream)."""
+    distributed = comm.kind != "none"
+    return {"per_rank_pairs_per_s": {"min": comm.min(rate_local), "max": comm.max(rate_local)} if distributed else None,
+            "gather_ms_per_step": 1e3 * gather_s / max(steps, 1) if gather_s is not None else None}
+
+
 def measure(opt, ctx, comm, rank, world):
     """One bench line: set the workload up, time `opt.steps` steps, check parity; -> dict on rank 0, None elsewhere.
     `opt`: config, content, pairs, steps, warmup, cpu_baseline, content_sweep, pcie, parity_budget_s."""
@@ -390,8 +427,14 @@ def measure(opt, ctx, comm, rank, world):
     cfg = CONFIGS[opt.config]
     H, W, bs, sw, proc, pnorm, seed, label = cfg
     gme = proc < 0
+    extra = EXTRA.get(opt.config, {})
+    fd = extra.get("fd", 1)
     B = opt.pairs if opt.pairs is not None else DEFAULT_PAIRS
     distributed = comm.kind != "none"
+    import motion as _motion
+    bs_before = _motion.BBME_BLOCK_SIZE
+    if gme:
+        _motion.BBME_BLOCK_SIZE = bs               # motion.py:9 is read at call time (the authors set 12 / 24 / 32 for their figures)
     # GME runs cut the resident pairs into `streams` ranges, each on its own HIP stream and host
     # thread: one range's host-side 3x3 solves are covered by the other ranges' kernels
     # (not for the exhaustive-search GME of configs[3]: its kernels run for tens of ms, the host gaps do
@@ -411,8 +454,14 @@ def measure(opt, ctx, comm, rank, world):
         B = shard.n_pairs                          # pairs of THIS rank; the step covers the whole sequence
     elif gme:
         import sequence
-        shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams, interleave=interleave)
-        shard.synth(seed, rank * B)                # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
+        if extra.get("content"):
+            frames, H, W = host_content(extra["content"], B + fd, H, W)
+            shard = sequence.ShardedSequence(H, W, B + fd, fd, ctx=ctx, streams=streams, interleave=interleave)
+            shard.load(frames)
+            del frames
+        else:
+            shard = sequence.ShardedSequence(H, W, B + 1, 1, ctx=ctx, streams=streams, interleave=interleave)
+            shard.synth(seed, rank * B)            # rank r holds frames t = r*B .. r*B+B (halo of fd=1 included)
     elif opt.content == "synthetic":
         seq = native.Sequence(ctx, B + 1, H, W)
         seq.synth(seed, rank * B)
@@ -433,7 +482,9 @@ def measure(opt, ctx, comm, rank, world):
             params, psnr = shard.estimate_and_compensate()
             rows = np.concatenate([params, psnr[:, None]], axis=1)
             last["local_rows"] = rows
+            t_g = time.perf_counter()
             last["rows"] = comm.gather_rows(rows, shard.n_pairs_total)     # the path's one exchange: 56 B per pair
+            last["gather_s"] = last.get("gather_s", 0.0) + time.perf_counter() - t_g
     elif gme:
         def step():
             # motion.global_motion_estimation + results.py:52-59,109 for every resident pair;
@@ -468,7 +519,10 @@ def measure(opt, ctx, comm, rank, world):
         def step():                                # the agreed fallback transport / the gloo rehearsal: rows via the host
             seq.invalidate_pyramids()
             seq.bbme(1, bs, sw, proc, pnorm)
-            rows = comm.gather_rows(seq.mv_summary(), world * B)
+            local = seq.mv_summary()
+            t_g = time.perf_counter()
+            rows = comm.gather_rows(local, world * B)
+            last["gather_s"] = last.get("gather_s", 0.0) + time.perf_counter() - t_g
             last["gathered"] = rows.reshape(world, B, 6)
     else:
         def step():
@@ -483,6 +537,7 @@ def measure(opt, ctx, comm, rank, world):
         finish()
     if shard is not None:
         shard.sync()
+    last.pop("gather_s", None)
     comm.barrier()
     ctx.timer_start()
     t0 = time.perf_counter()
@@ -497,11 +552,24 @@ def measure(opt, ctx, comm, rank, world):
     elapsed = time.perf_counter() - t0
     if gme:
         kernel_ms = 1e3 * elapsed / max(opt.steps, 1)     # several streams: the whole step on the wall clock
+    # N > 1: the slowest and the fastest rank (their own pairs over their own clock between the two barriers), and what the
+    # step's exchange costs: host-timed around the gather where it blocks; where it is queued behind the search (RCCL,
+    # block matching) five gathers are timed alone after the loop
+    rep = rank_report(comm, B * opt.steps / elapsed, last.get("gather_s"), opt.steps)
+    per_rank, gather_ms = rep["per_rank_pairs_per_s"], rep["gather_ms_per_step"]
+    if seq is not None and distributed and comm.rccl:
+        comm.barrier()
+        t_g = time.perf_counter()
+        for k in range(5):
+            seq.mv_summary_gather(B, world, slot=k & 1)
+            seq.wait()
+        gather_ms = 1e3 * (time.perf_counter() - t_g) / 5
     elapsed = comm.max(elapsed)
     if seq is not None and distributed and comm.rccl:
         seq.set_split_phase(False)
 
     def release():
+        _motion.BBME_BLOCK_SIZE = bs_before
         if seq is not None:
             seq.close()
         if shard is not None:
@@ -514,18 +582,16 @@ def measure(opt, ctx, comm, rank, world):
     from helpers import c_oracle, mv_summary_rows, oracle_results_flow
 
     # ---- parity gate printed with the number: sampled pairs (first and last included) against the C oracle
-    n_s = parity_sample_size(opt.config, opt.parity_budget_s)
+    n_s = parity_sample_size(opt.config, opt.parity_budget_s, getattr(opt, "parity_min_pairs", 3))
     parity = {"checker": "oracle/gme_oracle.c (C restatement pinned on the reference's goldens)"}
     t_par = time.perf_counter()
     if not gme:
         info = ctx.last_bbme_info()
         co = c_oracle()
         idx = sample_pairs(B, n_s)
-        bad = []
-        for p in idx:
-            got = seq.read_mv(p, 1)[0]
-            if not np.array_equal(got, co.bbme(seq.read_frame(p), seq.read_frame(p + 1), bs, sw, proc, pnorm)):
-                bad.append(p)
+        got = [(seq.read_mv(p, 1)[0], seq.read_frame(p), seq.read_frame(p + 1)) for p in idx]       # device reads: one thread
+        want = oracle_map(lambda t: co.bbme(t[1], t[2], bs, sw, proc, pnorm), got)
+        bad = [p for p, g, w in zip(idx, got, want) if not np.array_equal(g[0], w)]
         parity.update({"pairs_checked": len(idx), "first": idx[0], "last": idx[-1], "mismatching_pairs": bad, "ok": not bad,
                        "what": "motion-vector field, bit-exact"})
         gpath = os.path.join(REPO, "tests", "golden", "g2_synth720.npz")
@@ -563,11 +629,13 @@ def measure(opt, ctx, comm, rank, world):
         psnr = last["local_rows"][:, 6] if proc == -3 else last["psnr"]
         bad = []
         worst = 0.0
-        for p in idx:
+        inputs = []
+        for p in idx:                                   # device reads: one thread
             lane, k = shard._lane_of(p)
-            f0, f1 = lane.seq.read_frame(k), lane.seq.read_frame(k + 1)
-            wp, _, wc, wpsnr = oracle_results_flow(f0, f1, bs, 0 if proc == -2 else 3, sw if proc == -2 else 2)
-            ok = (np.allclose(params[p], wp, rtol=1e-10, atol=1e-12) and np.array_equal(shard.read_compensated(p), wc)
+            inputs.append((lane.seq.read_frame(k), lane.seq.read_frame(k + fd), shard.read_compensated(p)))
+        wants = oracle_map(lambda t: oracle_results_flow(t[0], t[1], bs, 0 if proc == -2 else 3, sw if proc == -2 else 2), inputs)
+        for p, t, (wp, _, wc, wpsnr) in zip(idx, inputs, wants):
+            ok = (np.allclose(params[p], wp, rtol=1e-10, atol=1e-12) and np.array_equal(t[2], wc)
                   and abs(psnr[p] - wpsnr) < 1e-9)
             worst = max(worst, float(np.max(np.abs(params[p] - wp))))
             if not ok:
@@ -610,11 +678,12 @@ def measure(opt, ctx, comm, rank, world):
         "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
         "ms_per_step": 1e3 * elapsed / opt.steps, "higher_is_better": True,
         "scaling": "strong" if proc == -3 else "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic" if opt.content == "synthetic" else opt.content,
-        "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": 1,
+        "vs_baseline": None, "dtype": "u8", "data": extra.get("content") or ("synthetic" if opt.content == "synthetic" else opt.content),
+        "config": {"workload": label, "pairs_per_step_per_gpu": B, "frame_distance": fd,
                    "sharding": "frame pairs across ranks, no data-path collective",
                    "streams_per_gpu": len(shard.lanes) if shard is not None else 1,
                    "collective": comm.kind, "exchange": exchange, "rccl_reports": comm.rccl_reports,
+                   "per_rank_pairs_per_s": per_rank, "gather_ms_per_step": gather_ms,
                    "multi_gpu_measured_by_builder": False},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -622,6 +691,8 @@ def measure(opt, ctx, comm, rank, world):
                      "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": abytes},
         "parity": parity,
     }
+    if comm.degraded:
+        out["degraded"] = comm.degraded             # `value` then is NOT the product path's exchange; bench.py exits non-zero
     if distributed and not gme:
         out["roofline"]["note"] = "kernel_ms_per_launch spans the step's search, summary kernel and all-gather (HIP events on the stream)"
     if gme:
@@ -631,11 +702,11 @@ def measure(opt, ctx, comm, rank, world):
         lane0 = shard.lanes[0]
         n0 = lane0.hi - lane0.lo
         p_proc, p_sw = (0, sw) if proc == -2 else (3, 2)
-        lane0.seq.bbme(1, bs, p_sw, p_proc, 1)
+        lane0.seq.bbme(fd, bs, p_sw, p_proc, 1)
         lane0.ctx.sync()
         lane0.ctx.timer_start()
         for _ in range(3):
-            lane0.seq.bbme(1, bs, p_sw, p_proc, 1)
+            lane0.seq.bbme(fd, bs, p_sw, p_proc, 1)
         k_ms = lane0.ctx.timer_stop() / 3
         kinfo = lane0.ctx.last_bbme_info()
         kbytes = algorithmic_bytes(H, W, bs, False) * n0
@@ -837,21 +908,34 @@ def secondary_block(ctx, comm):
     smaller parity sample, no CPU baseline): the driver's one default run then carries configs[2] / configs[3] numbers."""
     block = {}
     t0 = time.perf_counter()
-    for name, pairs, steps, warmup, par_s in SECONDARY:
+    for name, pairs, steps, warmup, par_s, par_min in SECONDARY:
         opt = types.SimpleNamespace(config=name, content="synthetic", pairs=pairs, steps=steps, warmup=warmup,
-                                    cpu_baseline=False, content_sweep=False, pcie=False, parity_budget_s=par_s)
+                                    cpu_baseline=False, content_sweep=False, pcie=False, parity_budget_s=par_s, parity_min_pairs=par_min)
         t1 = time.perf_counter()
+        comm1 = comm
         try:
-            d = measure(opt, ctx, comm, 0, 1)
+            if CONFIGS[name][4] == -3:
+                # BASELINE configs[4] at N = 1: the step's all-gather goes through the library's RCCL communicator
+                # (gme_shard_gather, world 1) exactly as at N > 1
+                os.environ["GME_BENCH_FORCE_DIST"] = "1"
+                try:
+                    comm1 = Comm(ctx, 0, 1, ctx.device)
+                finally:
+                    os.environ.pop("GME_BENCH_FORCE_DIST", None)
+            d = measure(opt, ctx, comm1, 0, 1)
         except Exception as e:                      # noqa: BLE001 -- one config must not take the headline line down
             block[name] = {"error": repr(e)}
             continue
+        finally:
+            if comm1 is not comm:
+                comm1.close()
         entry = {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "ms_per_step": d["ms_per_step"],
-                 "pairs_per_step": pairs, "steps": steps, "warmup": warmup, "streams": d["config"]["streams_per_gpu"],
+                 "pairs_per_step": d["config"]["pairs_per_step_per_gpu"], "steps": steps, "warmup": warmup, "streams": d["config"]["streams_per_gpu"],
                  "kernel": d["roofline"]["kernel"], "kernel_ms_per_launch": d["roofline"]["kernel_ms_per_launch"],
                  "hbm_frac_of_dominant_kernel": d["roofline"]["frac"],
                  "parity_ok": d["parity"]["ok"], "pairs_checked_vs_c_oracle": d["parity"]["pairs_checked"],
-                 "seconds": round(time.perf_counter() - t1, 1)}
+                 "first_and_last_pair_checked": [d["parity"]["first"], d["parity"]["last"]],
+                 "collective": d["config"]["collective"], "seconds": round(time.perf_counter() - t1, 1)}
         if "whole_step" in d["roofline"]:
             entry["whole_step_hbm_frac"] = d["roofline"]["whole_step"]["frac"]
         if "elimination" in d:
@@ -901,7 +985,10 @@ def main():
         if default_command and not args.no_secondary:
             out["secondary"] = secondary_block(ctx, comm)
         print(json.dumps(out), flush=True)
+    degraded = comm.degraded
     comm.close()
+    if degraded:                                    # every rank knows (the fallback is agreed collectively): the line is
+        sys.exit(3)                                 # printed, but a launch that did not use the C ABI's RCCL is not a pass
 
 
 if __name__ == "__main__":

@@ -15,16 +15,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgme_hip.so")
 
-GME_OK, ERR_ARG, ERR_INEXACT, ERR_GEOMETRY, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+GME_OK, ERR_ARG, ERR_GEOMETRY, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -3, -4, -5, -6
 
 
 class GmeError(RuntimeError):
     """HIP/runtime failure inside libgme_hip.so."""
-
-
-class GmeInexactError(ArithmeticError):
-    """Reserved (GME_ERR_INEXACT).  Outside float32's exact-integer range (MSE with bs > 16) the
-    kernels reproduce NumPy's float32 pairwise summation order, so nothing raises this today."""
 
 
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -118,8 +113,6 @@ def _raise(rc, lib):
     msg = (lib.gme_last_error() or b"").decode("utf-8", "replace")
     if rc == ERR_ARG:
         raise IndexError(msg)            # bbme.py:27,60 raise IndexError on bad table indices
-    if rc == ERR_INEXACT:
-        raise GmeInexactError(msg)
     if rc == ERR_GEOMETRY:
         raise AssertionError(msg)        # bbme.py:59
     if rc == ERR_NOMEM:

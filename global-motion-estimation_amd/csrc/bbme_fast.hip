@@ -174,8 +174,7 @@ __device__ __forceinline__ void qsad16_block(const FastDev& d, const uint32_t* w
         const int ce = local / R, i = local - ce * R;
         best = ((lbest >> 16) << 13) | (uint32_t)((q * 4 * R + ce) * NC + prow * R + i);
     }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m, 64));
+    best = wave_min_u32(best);                           // DPP: no lane-index registers hoisted out of the redo kernel's work loop
     if (lane == 0) {
         const int idx = best & 0x1FFF;
         const int ci = idx / NC, ri = idx - ci * NC;
@@ -219,11 +218,122 @@ struct RedoDev {
 //   sum(A^2)  64 v_dot4 + a wave reduction, once per block.
 // All terms are exact integers < 2^26 (bs = 16), equal to the reference's float32 sums (bbme.py:94).
 // ---------------------------------------------------------------------------
-template <int R, bool ALDS = false>
-__device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0, int tid,
-                                            const uint32_t* alds = nullptr)
+// One pass over the window for the column groups K0 .. K0+KN-1 of every lane (candidates 4k .. 4k+3 of its R rows): the
+// R x KN x 4 dot products, then the costs, folded into the lane's running minimum (bcost, blocal) in local scan order
+// ((4k+e) outer, i inner -- the groups are visited in ascending k, so a later pass only replaces a strictly smaller cost).
+// ROLL: the anchor rows are (scalar-)loaded as the window rows reach them and only the last R stay live (R x 4 scalars
+// instead of 64 -- inside the work loop of k_exh_redo16 the 64 did not fit beside everything else and went to VGPRs).
+template <int R, int K0, int KN, bool ROLL>
+__device__ __forceinline__ void dot16_part(const FastDev& d, const uint32_t* lrow, const_u32* anchor, int apitch,
+                                           SqTable sq, int tab0, bool interior, int prow, int q, int lo_r, int hi_r, int lo_c,
+                                           int hi_c, int r0, int c0, uint32_t a2, uint32_t& bcost, int& blocal)
 {
-    constexpr int NW = R + 4;                          // window dwords per lane and row
+    constexpr int NWP = KN + 4;                        // window dwords per lane and row for these groups
+    constexpr int AROWS = ROLL ? R : 16;
+    uint32_t acc[R][KN][4];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][k][e] = 0;
+    uint32_t A[AROWS][4];
+    if (ROLL) asm volatile("" : "+s"(apitch));        // opaque per pass: merged with the other passes' loads, all 64 anchor scalars
+                                                       // stay live from the first pass to the last and spill into VGPR lanes
+    if (!ROLL) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
+    }
+#pragma unroll
+    for (int t = 0; t < R + 15; ++t) {
+        uint32_t w[NWP];
+#pragma unroll
+        for (int s = 0; s < NWP; ++s) w[s] = lrow[t * d.pitch_dw + K0 + s];
+        if (ROLL && t < 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[t % AROWS][j] = anchor[t * apitch + j];
+        }
+        uint32_t sh[NWP - 1][4];                       // sh[s][e] = bytes 4(K0+s)+e .. +3 of the row
+#pragma unroll
+        for (int s = 0; s < NWP - 1; ++s) {
+            sh[s][0] = w[s];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) sh[s][e] = __builtin_amdgcn_alignbyte(w[s + 1], w[s], (uint32_t)e);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int a = t - i;
+            if (a < 0 || a > 15) continue;
+#pragma unroll
+            for (int k = 0; k < KN; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][k][e] = __builtin_amdgcn_udot4(sh[k + j][e], A[a % AROWS][j], acc[i][k][e], false);
+        }
+        // Pin this row's dot products before the next row's: an empty asm that "modifies" every
+        // accumulator.  Without it instruction selection linearises the unrolled body one
+        // accumulator chain at a time, keeps all 18 rows of shifted dwords live (> 256 VGPRs,
+        // spills) and pads the dependent v_dot4 chain with s_nops.
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int k = 0; k < KN; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(acc[i][k][e]));
+        if (ROLL) __builtin_amdgcn_sched_barrier(0);   // work loop: nothing of the next window row moves up into this one
+    }
+    // ---- costs and the first minimum in scan order (column index outer, row index inner) ----
+    // table positions as 32-bit offsets from the plane (uniform base + one VGPR; 64-bit indices cost an address pair per
+    // read, and the edge branch keeps R x KN x 4 guarded reads in flight)
+    if (interior) {
+        // whole window inside the frame: the four candidates 4k .. 4k+3 of a row share one 16-byte table read
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            uint32_t b2[R][4];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const uint4 v = *(const uint4*)(sq + (uint32_t)(tab0 + i * d.pitch + 4 * (K0 + k)));
+                b2[i][0] = v.x; b2[i][1] = v.y; b2[i][2] = v.z; b2[i][3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
+                    const uint32_t cost = a2 + b2[i][e] - 2u * acc[i][k][e];
+                    if (cost < bcost) { bcost = cost; blocal = (4 * (K0 + k) + e) * R + i; }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
+                    const int ri = prow * R + i, ci = q * 4 * R + 4 * (K0 + k) + e;
+                    if (ri >= lo_r && ri <= hi_r && ci >= lo_c && ci <= hi_c) {
+                        const uint32_t b2 = sq[(uint32_t)((r0 - d.sw + ri) * d.pitch + (c0 - d.sw + ci))];
+                        const uint32_t cost = a2 + b2 - 2u * acc[i][k][e];
+                        if (cost < bcost) { bcost = cost; blocal = (4 * (K0 + k) + e) * R + i; }
+                    }
+                }
+            if (ROLL) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// KS = column groups per pass over the window.  KS = R is the one-pass form (k_exh_dot16: a kernel of its own may take
+// 166 VGPRs at R = 5); the work-loop kernel k_exh_redo16 runs R = 3 .. 5 in passes of two groups -- R x 2 x 4 accumulators
+// instead of R x R x 4 (100 at R = 5, which spilled 215 VGPRs to scratch inside the 128 that four waves per SIMD allow,
+// VERDICT r3 #2) -- at the price of the window's dwords and their byte shifts being fetched once per pass (v_dot4 work, 94 %
+// of the body, is unchanged).
+template <int R, int KS = R>
+__device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* win, int pair, int brow, int bcol0, int tid)
+{
     const int r0 = brow * 16;
     const int NC = 2 * d.sw + 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,123 +344,44 @@ __device__ __forceinline__ void dot16_block(const FastDev& d, const uint32_t* wi
     const int prow = lane >> 2, q = lane & 3;
 
     const uint8_t* aptr = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
-    const_u32* anchor = as_constant(aptr);
+    // wave-uniform by construction (pair, row, wave); said explicitly so that the anchor reads stay scalar loads
+    const unsigned long long abits = (unsigned long long)aptr;
+    const_u32* anchor = as_constant((const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(abits >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((int)abits)));
     const int apitch = d.pitch >> 2;
-    uint32_t A[16][4];
-    if (!ALDS) {
-#pragma unroll
-        for (int a = 0; a < 16; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) A[a][j] = anchor[a * apitch + j];
-    }
     // sum of squares of the anchor: lane l takes dword l of the block
     uint32_t a2;
     {
-        const uint32_t mine = ALDS ? alds[wave * 64 + lane] : *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
-        a2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) a2 += (uint32_t)__shfl_xor((int)a2, m, 64);
-    }
-
-    uint32_t acc[R][R][4];
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][k][e] = 0;
+        const uint32_t mine = *(const uint32_t*)(aptr + (long long)(lane >> 2) * d.pitch + (lane & 3) * 4);
+        a2 = wave_sum_u32(__builtin_amdgcn_udot4(mine, mine, 0u, false));      // DPP: no lane-index registers (ds_bpermute
+    }                                                                           // addresses were hoisted out of the work loop and spilled)
 
     const uint32_t* lrow = win + (prow * R) * d.pitch_dw + wave * 4 + q * R;
-#pragma unroll
-    for (int t = 0; t < R + 15; ++t) {
-        uint32_t w[NW];
-#pragma unroll
-        for (int s = 0; s < NW; ++s) w[s] = lrow[t * d.pitch_dw + s];
-        if (ALDS && t < 16) {
-            // volatile: keeps the read at this step (hoisted to the top, all 16 rows would be live at once)
-            const u32x4_v v = *(const volatile u32x4_v*)(alds + wave * 64 + t * 4);
-            A[t][0] = v.x; A[t][1] = v.y; A[t][2] = v.z; A[t][3] = v.w;
-        }
-        uint32_t sh[NW - 1][4];                        // sh[s][e] = bytes 4s+e .. 4s+e+3 of the row
-#pragma unroll
-        for (int s = 0; s < NW - 1; ++s) {
-            sh[s][0] = w[s];
-#pragma unroll
-            for (int e = 1; e < 4; ++e) sh[s][e] = __builtin_amdgcn_alignbyte(w[s + 1], w[s], (uint32_t)e);
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int a = t - i;
-            if (a < 0 || a > 15) continue;
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[i][k][e] = __builtin_amdgcn_udot4(sh[k + j][e], A[a][j], acc[i][k][e], false);
-        }
-        // Pin this row's dot products before the next row's: an empty asm that "modifies" every
-        // accumulator.  Without it instruction selection linearises the unrolled body one
-        // accumulator chain at a time, keeps all 18 rows of shifted dwords live (> 256 VGPRs,
-        // spills) and pads the dependent v_dot4 chain with s_nops.
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(acc[i][k][e]));
-    }
-
-    // ---- costs and the first minimum in scan order (column index outer, row index inner) ----
     const int lo_r = max(0, d.sw - r0), hi_r = min(NC - 1, d.H - 16 - r0 + d.sw);
     const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
     const SqTable sq = sq_table(d.sqbox + (long long)pair * d.sqbox_stride, d.H, d.pitch);
+    const int tab0 = (r0 - d.sw + prow * R) * d.pitch + (c0 - d.sw + q * 4 * R);       // >= 0 for interior blocks (only they use it)
     uint32_t bcost = 0xFFFFFFFFu;
     int blocal = 0;
     const bool interior = __builtin_amdgcn_readfirstlane(lo_r == 0 && lo_c == 0 && hi_r == 16 * R - 1 && hi_c == 16 * R - 1);
-    if (interior) {
-        // whole window inside the frame: the four candidates 4k .. 4k+3 of a row share one 8-byte + one 4-byte table read
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            uint32_t b2[R][4];
-#pragma unroll
-            for (int i = 0; i < R; ++i) sq4(sq, (long long)(r0 - d.sw + prow * R + i) * d.pitch + (c0 - d.sw + q * 4 * R + 4 * k), b2[i]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
-                    const uint32_t cost = a2 + b2[i][e] - 2u * acc[i][k][e];
-                    if (cost < bcost) { bcost = cost; blocal = (4 * k + e) * R + i; }
-                }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < R; ++i) {          // local scan order: (4k+e) outer, i inner
-                    const int ri = prow * R + i, ci = q * 4 * R + 4 * k + e;
-                    if (ri >= lo_r && ri <= hi_r && ci >= lo_c && ci <= hi_c) {
-                        const uint32_t b2 = sq1(sq, (long long)(r0 - d.sw + ri) * d.pitch + (c0 - d.sw + ci));
-                        const uint32_t cost = a2 + b2 - 2u * acc[i][k][e];
-                        if (cost < bcost) { bcost = cost; blocal = (4 * k + e) * R + i; }
-                    }
-                }
-    }
-    unsigned long long best = ~0ull;
-    if (bcost != 0xFFFFFFFFu) {
+#define DOT16_PART(K0) \
+    if constexpr ((K0) < R) dot16_part<R, (K0), ((K0) + KS <= R ? KS : R - (K0)), (KS < R)>(d, lrow, anchor, apitch, sq, tab0, interior, prow, q, \
+                                                                                         lo_r, hi_r, lo_c, hi_c, r0, c0, a2, bcost, blocal)
+    DOT16_PART(0);
+    DOT16_PART(KS);
+    DOT16_PART(2 * KS);
+    DOT16_PART(3 * KS);
+    DOT16_PART(4 * KS);
+#undef DOT16_PART
+    // the smallest (cost << 13 | scan index) of the wave in two 32-bit steps: the smallest cost, then the smallest scan index
+    // among the lanes that hold it (bbme.py:171: the first minimum in scan order)
+    const uint32_t cmin = wave_min_u32(bcost);
+    uint32_t myidx = 0xFFFFFFFFu;
+    if (bcost == cmin && bcost != 0xFFFFFFFFu) {
         const int ce = blocal / R, i = blocal - ce * R;
-        best = ((unsigned long long)bcost << 13) | (unsigned)((q * 4 * R + ce) * NC + prow * R + i);
+        myidx = (uint32_t)((q * 4 * R + ce) * NC + prow * R + i);
     }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, m, 64);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), m, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        best = o < best ? o : best;
-    }
+    const uint32_t best = wave_min_u32(myidx);
     if (lane == 0) {
         const int idx = (int)(best & 0x1FFF);
         const int ci = idx / NC, ri = idx - ci * NC;
@@ -375,11 +406,17 @@ __global__ void __launch_bounds__(384) k_exh_dot16(FastDev d)
     dot16_block<R>(d, win, pair, brow, bcol0, (int)threadIdx.x);
 }
 
+#ifndef REDO_KS5
+// column groups per pass of the R = 5 MSE body: 2 -> 128 VGPRs, 4 waves per SIMD; 1 -> 96 VGPRs, 5 waves (both: no spill, no scratch).
+// Same box, 128 pairs of 1080p noise, sw 32: 6.29 k pairs/s with 2, 6.01 k with 1 (the fifth wave does not pay for three more
+// passes over the window), 4.37 k for round 3's one-pass body (215 VGPRs spilled to 192 bytes of scratch per lane).
+#define REDO_KS5 2
+#endif
 // The work-loop form of the two bodies above.  The anchors stay scalar here too (constant address space, see
 // as_constant): with plain global loads the compiler moved them to VGPRs inside the loop (86-128 per wave), round 2
 // staged them in LDS instead (82 / 117 VGPRs: 5 / 4 waves per SIMD).
 template <int R, bool MSE>
-__global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
+__global__ void __launch_bounds__(1024, (MSE && (R == 4 || (R == 5 && REDO_KS5 == 1)) ? 5 : 4)) k_exh_redo16(FastDev d, RedoDev r)
 {
     extern __shared__ uint32_t win[];
     __shared__ uint32_t item_s;
@@ -401,11 +438,11 @@ __global__ void __launch_bounds__(1024, 4) k_exh_redo16(FastDev d, RedoDev r)
         // per SIMD, +2.8 % on noise).  The MAE body is better off with the hoisting (72 VGPRs either way 7 waves; 9 scalar
         // spills and -1.8 % with the opaque copy).
         int tid = (int)threadIdx.x;
-        if (MSE) asm volatile("" : "+v"(tid));
+        if (MSE || R == 5) asm volatile("" : "+v"(tid));     // (MAE at R = 5: 128 VGPRs + 2 spilled without it)
         if (ok) stage_window(d, win, d.cur + (long long)pair * d.plane_stride, bcol0, brow * 16, tid);
         __syncthreads();
         if (ok) {
-            if (MSE) dot16_block<R>(d, win, pair, brow, bcol0, tid);
+            if (MSE) dot16_block<R, (R >= 5 ? REDO_KS5 : R >= 3 ? 2 : R)>(d, win, pair, brow, bcol0, tid);
             else qsad16_block<R>(d, win, pair, brow, bcol0, tid);
         }
         __syncthreads();                                   // the next item restages `win` and redraws item_s

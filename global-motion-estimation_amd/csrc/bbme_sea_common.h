@@ -61,29 +61,8 @@ struct SeaDev {
 
 typedef uint64_t u64_a4 __attribute__((aligned(4)));
 
-// Wave-wide reductions without LDS traffic: four DPP steps leave every lane with the result of its
-// 16-lane row (xor 1, xor 2 inside quads, then the two mirrors), v_readlane + SALU combine the four rows.
-#define SEA_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, false))
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-    v = min(v, SEA_DPP(v, 0xB1));                          // quad_perm [1,0,3,2]
-    v = min(v, SEA_DPP(v, 0x4E));                          // quad_perm [2,3,0,1]
-    v = min(v, SEA_DPP(v, 0x141));                         // row_half_mirror
-    v = min(v, SEA_DPP(v, 0x140));                         // row_mirror
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return min(min(r0, r1), min(r2, r3));
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-    v += SEA_DPP(v, 0xB1);
-    v += SEA_DPP(v, 0x4E);
-    v += SEA_DPP(v, 0x141);
-    v += SEA_DPP(v, 0x140);
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
-           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
+// wave_min_u32 / wave_sum_u32 (DPP reductions): gme_internal.h
+#define SEA_DPP(v, ctrl) GME_DPP(v, ctrl)
 
 // n / dv for n < 4096 and dv < 256 without the 20-odd instructions of an emulated division:
 // magic = 2^20 / dv + 1 overshoots the reciprocal by < 2^-20, so the product is off by < 2^-8 < 1 / dv.

@@ -26,6 +26,14 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned long long u64min_(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
 
+// per 16-bit half: a * b + c  (the compiler splits `a * 2 - c` into a shift and a subtraction)
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+
 // B: as lower_bounds() of bbme_sea.hip, with the squared bound: key = floor(sum_q dS_q^2 / 32) << 7 | local index.
 template <int R, bool GUARD>
 __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, int prow, int q, uint32_t a01, uint32_t a23,
@@ -52,10 +60,13 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
                     const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
                     const uint32_t tp = __builtin_amdgcn_perm((uint32_t)(t[k + 2] >> (32 * (e >> 1))), (uint32_t)(t[k] >> (32 * (e >> 1))), sel);
                     const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b[k + 2] >> (32 * (e >> 1))), (uint32_t)(b[k] >> (32 * (e >> 1))), sel);
-                    const s16x2 dt = __builtin_bit_cast(s16x2, tp) - __builtin_bit_cast(s16x2, a01);   // |d| <= 16320
-                    const s16x2 db = __builtin_bit_cast(s16x2, bt) - __builtin_bit_cast(s16x2, a23);
-                    const uint32_t lbx = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
-                    pkey[k] = min(pkey[k], ((lbx >> 5) << 7) + (uint32_t)((4 * k + e) * R + i));      // local < 4R*R <= 100 < 128
+                    // twice the differences (one v_pk_mad_i16 each, as many instructions as the subtraction): the squares then
+                    // sum to 4 LBx < 2^32, whose bits 7.. ARE floor(LBx / 32) -- one v_and_or builds the key where
+                    // (lbx >> 5) << 7 needed a shift and a shift-add (round 4: 9 -> 8 instructions per candidate)
+                    const s16x2 dt = __builtin_bit_cast(s16x2, pk_mad_i16(tp, 0x00020002u, a01));    // a01, a23: MINUS twice the anchor's sums; |d| <= 32640
+                    const s16x2 db = __builtin_bit_cast(s16x2, pk_mad_i16(bt, 0x00020002u, a23));
+                    const uint32_t lbx4 = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
+                    pkey[k] = min(pkey[k], (lbx4 & ~127u) | (uint32_t)((4 * k + e) * R + i));          // local < 4R*R <= 100 < 128
                 }
             }
         }
@@ -186,16 +197,21 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         if (active) {
             const uint32_t* lrow = win + (16 * wr2 + prow2 * R + AR * sub) * d.pitch_dw + wc2 * 4 + q2 * R + k2;
             const uint32_t* an = anchor + w2 * ANCHOR_STRIDE + AR * 4 * sub;
+            // anchor rows t - i meet window row t: each row is read ONCE, when it enters (i = 0), and stays in `keep` for the
+            // R - 1 window rows that follow (round 4: the per-(t, i) reads were not merged by the compiler -- 48 b128 LDS
+            // reads per patch, now 16)
+            u32x4 keep[R];
 #pragma unroll
             for (int t = 0; t < R + AR - 1; ++t) {
                 uint32_t w[5];
 #pragma unroll
                 for (int s = 0; s < 5; ++s) w[s] = lrow[t * d.pitch_dw + s];
+                if (t <= AR - 1) keep[t % R] = *(const u32x4*)(an + t * 4);
                 u32x4 ar[R];                               // anchor rows t - i that meet this window row
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int a = t - i;
-                    if (a >= 0 && a <= AR - 1) ar[i] = *(const u32x4*)(an + a * 4);
+                    if (a >= 0 && a <= AR - 1) ar[i] = keep[a % R];
                 }
                 // one window dword at a time: its four byte alignments (bytes 4j+e4 .. 4j+e4+3) live in four
                 // registers and feed the R x 4 accumulators, then the next dword reuses them
@@ -293,6 +309,9 @@ struct MseTile {
         if (wave_ok) {
             lds[L.anchor + wave * ANCHOR_STRIDE + lane] = mine;
             anchor_quadrants(mine, &p.a01, &p.a23);
+            // minus twice the sums, per half (<= 16320 each, so doubling does not carry): the addend of lower_bounds_mse's v_pk_mad_i16
+            p.a01 = __builtin_bit_cast(uint32_t, -(__builtin_bit_cast(s16x2, p.a01 << 1)));
+            p.a23 = __builtin_bit_cast(uint32_t, -(__builtin_bit_cast(s16x2, p.a23 << 1)));
             p.mine2 = __builtin_amdgcn_udot4(mine, mine, 0u, false);
             const uint32_t a2 = wave_sum_u32(p.mine2);
             if (lane == 0) lds[L.a2 + wave] = a2;

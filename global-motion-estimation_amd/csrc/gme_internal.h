@@ -151,6 +151,44 @@ int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int
 // was tried in round 3: the table kernel's two narrower stores per row made IT 17 % slower, 1.43 against 1.22 ms per 2049
 // frames of 720x480, and the whole MSE search 4 %.)
 #ifdef __HIPCC__
+// Wave-wide reductions without LDS traffic: four DPP steps leave every lane with the result of its 16-lane row (xor 1,
+// xor 2 inside quads, then the two mirrors); row_bcast:15 folds rows 0 and 2 into rows 1 and 3, row_bcast:31 folds row 1
+// into row 3, and one v_readlane of lane 63 makes the result scalar (round 4: 7 instead of 11 instructions; rounds 1-3
+// read one lane of every row and combined them on the scalar side).
+#define GME_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, false))
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, GME_DPP(v, 0xB1));                          // quad_perm [1,0,3,2]
+    v = min(v, GME_DPP(v, 0x4E));                          // quad_perm [2,3,0,1]
+    v = min(v, GME_DPP(v, 0x141));                         // row_half_mirror
+    v = min(v, GME_DPP(v, 0x140));                         // row_mirror
+#ifdef GME_WAVE_REDUCE_READLANES
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+#else
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));     // row_bcast:15 -> rows 1, 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));     // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += GME_DPP(v, 0xB1);
+    v += GME_DPP(v, 0x4E);
+    v += GME_DPP(v, 0x141);
+    v += GME_DPP(v, 0x140);
+#ifdef GME_WAVE_REDUCE_READLANES
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+#else
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);             // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);             // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
 typedef const uint32_t* SqTable;
 __device__ __forceinline__ SqTable sq_table(const uint32_t* slot, int, int) { return slot; }
 __device__ __forceinline__ uint32_t sq1(SqTable t, long long idx) { return t[idx]; }

@@ -47,7 +47,8 @@ typedef struct gme_seq gme_seq;   /* a frame sequence resident in HBM + per-pair
 enum {
     GME_OK = 0,
     GME_ERR_ARG = -1,        /* bad pointer / size / index (reference: IndexError, bbme.py:27,60) */
-    GME_ERR_INEXACT = -2,    /* reserved: outside float32's exact-integer range (bbme.py:61-64) the kernels now sum in NumPy's float32 order */
+    /* -2 is unused (rounds 1-3 reserved it for "inexact": outside float32's exact-integer range, bbme.py:61-64, the kernels
+     * sum in NumPy's float32 order instead of refusing) */
     GME_ERR_GEOMETRY = -3,   /* frame smaller than the search needs (reference: AssertionError, bbme.py:59) */
     GME_ERR_HIP = -4,        /* HIP runtime failure */
     GME_ERR_STATE = -5,      /* call order violated (e.g. fit before begin) */

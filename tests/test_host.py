@@ -169,6 +169,59 @@ def test_gather_over_gloo_world_2(tmp_path):
     assert "rank0 ok" in out.stdout and "rank1 ok" in out.stdout
 
 
+_BENCH_COMM = r"""
+import os, sys
+sys.path[:0] = [%(repo)r, %(pkg)r, %(tests)r]
+import numpy as np
+import bench, sequence
+class FakeCtx:                       # bench.Comm only syncs the context before a barrier
+    def sync(self): pass
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+if mode == "fallback":               # the C-ABI communicator is refused on every rank: the agreed fallback must be LABELLED
+    def refuse(ctx, r, w, timeout_s=180.0):
+        raise sequence.CommUnavailable("probe failed on 1 of 2 ranks (rank 1: OSError('no librccl'))")
+    sequence.comm_init = refuse
+    real = bench.Comm._torch_init
+    bench.Comm._torch_init = lambda self, backend, r, w, l: real(self, "gloo" if backend == "nccl" else backend, r, w, l)
+    os.environ.pop("GME_BENCH_BACKEND", None)
+comm = bench.Comm(FakeCtx(), rank, world, 0)
+rep = bench.rank_report(comm, 1000.0 * (rank + 1), 0.25 * (rank + 1), 5)
+rows = comm.gather_rows(np.full((3 + rank, 7), float(rank)), 7)
+assert rows.shape == (7, 7) and list(rows[:, 0]) == [0.0] * 3 + [1.0] * 4, rows
+sys.stdout.write("rank%%d kind=%%s degraded=%%s per_rank=%%s gather_ms=%%s;\n" %% (rank, comm.kind, comm.degraded, rep["per_rank_pairs_per_s"], rep["gather_ms_per_step"]))
+sys.stdout.flush()
+comm.close()
+"""
+
+
+@pytest.mark.parametrize("mode", ["gloo", "fallback"])
+def test_bench_line_fields_of_a_two_rank_launch(tmp_path, mode):
+    """an N > 1 line describes itself -- the slowest and the fastest rank's pairs/s, the exchange's ms per
+    step, and `degraded` when the rows did not travel over the C ABI's RCCL communicator (bench.py then exits 3 after
+    printing).  Two gloo ranks on the CPU: bench.Comm + bench.rank_report, the gather of ragged shards."""
+    script = tmp_path / "bench_comm.py"
+    script.write_text(_BENCH_COMM % {"repo": REPO, "pkg": os.path.join(REPO, "global-motion-estimation_amd"), "tests": os.path.join(REPO, "tests")})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", GME_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), mode],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for r in (0, 1):
+        import re
+        line = re.findall(r"rank%d kind=.*?;" % r, out.stdout, re.S)          # two processes share the pipe: lines may abut
+        assert line, out.stdout + out.stderr
+        assert "kind=torch.distributed/gloo" in line[0]
+        assert "per_rank={'min': 1000.0, 'max': 2000.0}" in line[0], line[0]
+        assert "gather_ms=%s;" % (50.0 * (r + 1)) in line[0], line[0]
+        if mode == "gloo":
+            assert "degraded=None" in line[0], line[0]
+        else:
+            assert "degraded=torch.distributed fallback (C-ABI RCCL communicator unavailable: probe failed on 1 of 2 ranks" in line[0], line[0]
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert 'out["degraded"] = comm.degraded' in src and "sys.exit(3)" in src
+
+
 def test_synth_generator_self_checks():
     """SURVEY.md §8(d) constants."""
     import synth
