@@ -412,6 +412,40 @@ class Comm:
         self.kind = "none"
 
 
+def hostile_1080(ctx, n=48):
+    """the hostile floor of BASELINE configs[3]'s geometry in the driver's line -- `n` pairs of 1920x1080 uniform
+    noise, bs 16, sw 32, both norms: nothing correlates, the elimination kernel hands (almost) every tile to the brute-force
+    redo kernel (k_exh_redo16<5, .>).  First and last pair against the C oracle."""
+    import _gme_native as native
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import c_oracle
+    H, W, bs, sw = 1080, 1920, 16, 32
+    fr, _, _ = host_content("noise", n + 1, H, W)
+    s2 = native.Sequence.from_frames(ctx, fr)
+    co = c_oracle()
+    out = {}
+    for pn, name in ((0, "mae"), (1, "mse")):
+        for _ in range(2):
+            s2.invalidate_pyramids()
+            s2.bbme(1, bs, sw, 0, pn)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(4):
+            s2.invalidate_pyramids()
+            s2.bbme(1, bs, sw, 0, pn)
+        ms = ctx.timer_stop() / 4
+        inf = ctx.last_bbme_info()
+        chk = [0, n - 1]
+        got = [s2.read_mv(p, 1)[0] for p in chk]
+        want = oracle_map(lambda p: co.bbme(fr[p], fr[p + 1], bs, sw, 0, pn), chk)
+        out[name] = {"frame": "%dx%d" % (W, H), "content": CONTENT_NOTE["noise"], "pairs": n, "pairs_per_s": n / (ms * 1e-3),
+                     "kernel": inf["plan"].split(" grid")[0], "tiles_redone_by_brute_force": inf["redo_tiles"],
+                     "surviving_fraction": inf["surviving"] / inf["patches"] if inf["patches"] else None,
+                     "parity_ok_sampled": bool(all(np.array_equal(g, w) for g, w in zip(got, want))), "pairs_checked_vs_c_oracle": len(chk)}
+    s2.close()
+    return out
+
+
 def rank_report(comm, rate_local, gather_s, steps):
     """What an N > 1 line says about its ranks: the slowest and the fastest rank's own pairs/s (collective: every rank
     calls it) and the host-timed cost of the step's exchange on this rank (None where the exchange is queued on the stream)."""
@@ -798,9 +832,12 @@ def measure(opt, ctx, comm, rank, world):
                                "parity_ok_sampled": bool(ok)}
                 s2.close()
             return sweep
-        out["content_sweep"] = sweep_of(pnorm, ("race", "pan240x2", "pan240seq", "noise", "flat"))
+        # real content = the reference's 51 distinct pan240 frames (320x240, and upscaled x2 to 640x480); the two-frame `race`
+        # pair of rounds 2-3 stays available as --content race
+        out["content_sweep"] = sweep_of(pnorm, ("pan240x2", "pan240seq", "noise", "flat"))
         if opt.config == "exh720":
             out["content_sweep_mse"] = sweep_of(1, ("pan240x2", "noise"))
+            out["content_sweep_1080p_noise"] = hostile_1080(ctx)
 
     if proc >= 0 and world == 1 and opt.pcie:
         # host-buffer (PCIe-inclusive) rate, NOT `value`: frames cross to the device, the fields

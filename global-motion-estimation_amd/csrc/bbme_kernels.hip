@@ -291,6 +291,186 @@ __global__ void __launch_bounds__(256) k_walk(Dev d)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Walk searches for block sizes 4, 8, 12, 20 .. 32 (multiples of 4 other than 16, costs inside float32's exact-integer
+// range): the sizes the reference itself runs besides 16 -- get_motion_field's default block_size=4 (bbme.py:15-18) and
+// the authors' BBME_BLOCK_SIZE = 12 / 24 / 32 (motion.py:9, docs/presentation/main.tex:382,426,558).  Same control flow as
+// k_walk<G> above (candidate order, clamps, first strict minimum: bbme.py:182-534), a different block distance:
+//   * G = 1 / 2 / 4 / 8 lanes per block, each lane owning whole block ROWS (lig, lig + G, ...): its anchor rows live in
+//     registers for the whole walk (BS / 4 dwords each);
+//   * a candidate row is BS / 4 + 1 aligned dwords of `cur` (the frames of a pair are L2-resident) turned into the
+//     BS / 4 unaligned ones by v_alignbyte_b32, then one v_sad_u8 (MAE) or three v_dot4_u32_u8 (MSE:
+//     sum a^2 + sum b^2 - 2 sum ab) per dword -- k_walk<G> reads single bytes and accumulates in 64 bits;
+//   * the G partial costs are added with DPP moves inside the group (32-bit: BS^2 * 65025 < 2^32 for BS <= 32).
+// A 16-byte row read may run up to 3 bytes past the block's right edge: inside the pitch padding, or into the next row /
+// the guard row behind every plane (plane_alloc) -- those bytes are shifted out by v_alignbyte.
+// ---------------------------------------------------------------------------
+template <int BS> struct WalkQ {
+    static constexpr int G = BS <= 4 ? 1 : BS <= 8 ? 2 : BS <= 16 ? 4 : 8;      // lanes per block
+    static constexpr int RPL = (BS + G - 1) / G;                                 // block rows per lane
+    static constexpr int DW = BS / 4;                                            // dwords per block row
+};
+
+template <int G>
+__device__ __forceinline__ unsigned groupq_sum(unsigned v)
+{
+    if (G >= 2) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    if (G >= 4) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    if (G >= 8) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    return v;
+}
+
+template <int BS, int PNORM>
+__global__ void __launch_bounds__(256) k_walkq(Dev d)
+{
+    constexpr int G = WalkQ<BS>::G, RPL = WalkQ<BS>::RPL, DW = WalkQ<BS>::DW;
+    const int nblk = d.nbr * d.nbc;
+    const long long total = (long long)nblk * d.pairs;
+    const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lig = threadIdx.x % G;
+    const bool active = gid < total;
+    const long long g = active ? gid : 0;
+    const int pair = (int)(g / nblk), blk = (int)(g % nblk);
+    const int r0 = (blk / d.nbc) * BS, c0 = (blk % d.nbc) * BS;
+    const uint8_t* cur = d.cur + (long long)pair * d.plane_stride;
+    const uint8_t* anchor = d.prev + (long long)pair * d.plane_stride + (long long)r0 * d.pitch + c0;
+    const int H = d.H, W = d.W, pitch = d.pitch;
+    const unsigned INF = 0xFFFFFFFFu;
+    const int cap = 2 * (H + W) + 64;       // walks strictly decrease the cost; this is a guard
+    bool overrun = false;
+    int out0 = 0, out1 = 0;
+
+    // this lane's anchor rows (block origins are multiples of 4: aligned dwords) and, for MSE, their sum of squares
+    uint32_t a[RPL][DW];
+    unsigned aa = 0;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int row = lig + G * j;
+#pragma unroll
+        for (int k = 0; k < DW; ++k) {
+            a[j][k] = (BS % G == 0 || row < BS) ? *(const uint32_t*)(anchor + (long long)row * pitch + 4 * k) : 0u;
+            if (PNORM == 1) aa = __builtin_amdgcn_udot4(a[j][k], a[j][k], aa, false);
+        }
+    }
+
+    auto cost_at = [&](int rr, int cc) -> unsigned {
+        const uint8_t* p = cur + (long long)(rr + lig) * pitch + (cc & ~3);
+        const uint32_t sh = (uint32_t)cc & 3u;
+        unsigned part = PNORM == 1 ? aa : 0u, ab = 0;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            if (BS % G != 0 && lig + G * j >= BS) break;                 // ragged last row group (BS = 12 with G = 8 never happens; BS = 20, 28)
+            uint32_t l[DW + 1];
+#pragma unroll
+            for (int k = 0; k <= DW; ++k) l[k] = *(const uint32_t*)(p + (long long)(G * j) * pitch + 4 * k);
+#pragma unroll
+            for (int k = 0; k < DW; ++k) {
+                const uint32_t b = __builtin_amdgcn_alignbyte(l[k + 1], l[k], sh);
+                if (PNORM == 0) part = __builtin_amdgcn_sad_u8(a[j][k], b, part);
+                else {
+                    part = __builtin_amdgcn_udot4(b, b, part, false);
+                    ab = __builtin_amdgcn_udot4(a[j][k], b, ab, false);
+                }
+            }
+        }
+        if (PNORM == 1) part -= 2u * ab;                                  // this lane's rows: sum (a - b)^2 >= 0
+        return groupq_sum<G>(part);
+    };
+#define INSIDE(rr, cc) ((rr) >= 0 && (cc) >= 0 && (rr) + BS <= H && (cc) + BS <= W)
+
+    if (d.procedure == GME_SEARCH_DIAMOND) {           // bbme.py:436-534
+        const int maxr = H - BS - 1, maxc = W - BS - 1;
+        int pr = r0, pc = c0, br = r0, bc = c0;
+        bool done = !active;
+        int it = 0;
+        while (__any(!done)) {
+            unsigned best = INF;
+            int nr = pr, nc = pc;
+            for (int k = 0; k < 9; ++k) {
+                const int rr = clamp_ref(pr + c_ldsp[k][0], maxr), cc = clamp_ref(pc + c_ldsp[k][1], maxc);
+                const unsigned c = cost_at(rr, cc);
+                if (c < best) { best = c; nr = rr; nc = cc; }
+            }
+            if (!done) {
+                done = (nr == pr && nc == pc);
+                pr = nr; pc = nc;
+            }
+            if (++it > cap) { overrun = true; break; }
+        }
+        unsigned best = INF;
+        br = pr; bc = pc;
+        for (int k = 0; k < 5; ++k) {                  // offsets applied swapped, bbme.py:518-521
+            const int rr = clamp_ref(pr + c_sdsp[k][1], maxr), cc = clamp_ref(pc + c_sdsp[k][0], maxc);
+            const unsigned c = cost_at(rr, cc);
+            if (c < best) { best = c; br = rr; bc = cc; }
+        }
+        out1 = br - r0; out0 = bc - c0;
+    } else if (d.procedure == GME_SEARCH_THREESTEP) {  // bbme.py:182-341
+        const int n = 2 * d.sw + BS;
+        const int steps[3] = { (int)(n / 3.0), (int)(n / 5.0), (int)(n / 10.0) };
+        int drow = 0, dcol = 0, trow = 0, tcol = 0;
+        int org_r = r0, org_c = c0;
+        for (int s = 0; s < 3; ++s) {
+            const int st = steps[s];
+            unsigned best = INF;
+            int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;
+            for (int a2 = -1; a2 <= 1; ++a2)
+                for (int b2 = -1; b2 <= 1; ++b2) {
+                    const int wc = a2 * st, wr = b2 * st;
+                    const int rr = org_r + wr, cc = org_c + wc;
+                    // every lane of the wave must take part in the DPP moves of cost_at
+                    const bool ok = INSIDE(rr, cc);
+                    const unsigned c = cost_at(ok ? rr : r0, ok ? cc : c0);
+                    if (ok && c < best) { best = c; kr = wr; kc = wc; }
+                }
+            if (s == 0) { drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol; }
+            else {
+                trow = kr; tcol = kc;
+                drow += trow; dcol += tcol;
+                org_r += drow; org_c += dcol;          // bbme.py:300-301 (accumulated again)
+            }
+        }
+        out0 = dcol; out1 = drow;
+    } else {                                           // 2-D log, bbme.py:344-433
+        int br = 0, bc = 0, pr = r0, pc = c0;
+        int step = active ? d.sw : 0;
+        int it = 0;
+        while (__any(step > 1)) {
+            const bool cross = step > 2;
+            unsigned best = INF;
+            int nr = br, nc = bc;
+            for (int k = 0; k < 9; ++k) {
+                int rr, cc;
+                if (cross) {
+                    if (k >= 5) break;
+                    rr = pr + (k == 1 ? step : k == 2 ? -step : 0);
+                    cc = pc + (k == 3 ? step : k == 4 ? -step : 0);
+                } else {
+                    rr = pr + (k / 3 - 1) * 2;
+                    cc = pc + (k % 3 - 1) * 2;
+                }
+                const bool ok = INSIDE(rr, cc);
+                const unsigned c = cost_at(ok ? rr : r0, ok ? cc : c0);
+                if (ok && c < best) { best = c; nr = rr; nc = cc; }
+            }
+            if (step > 1) {
+                br = nr; bc = nc;
+                if ((br == pr && bc == pc) || step == 2) step /= 2;
+                pr = br; pc = bc;
+            }
+            if (++it > cap) { overrun = true; break; }
+        }
+        out1 = br - r0; out0 = bc - c0;
+    }
+#undef INSIDE
+    if (overrun && lig == 0) atomicExch(d.status, 1);
+    if (active && lig == 0) {
+        int32_t* o = d.mf + gid * 2;
+        o[0] = out0; o[1] = out1;
+    }
+}
+
 }  // namespace
 
 // the `break` inside the 2-D log candidate loop is wave-divergent only between groups
@@ -392,6 +572,24 @@ static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
     if (job.procedure == GME_SEARCH_EXHAUSTIVE) {
         plan_note(ctx, 0, "k_exh_generic%s grid %lld", d.f32 ? " (float32-order costs)" : "", nblk * job.pairs);
         hipLaunchKernelGGL(k_exh_generic, dim3((unsigned)(nblk * job.pairs)), dim3(256), 0, ctx->stream, d);
+    } else if (!d.f32 && job.bs % 4 == 0 && job.bs >= 4 && job.bs <= 32 && job.bs != 16 && !getenv("GME_FORCE_GENERIC")) {
+        // the reference's other block sizes (k_walkq above); 16 has k_walk16 / k_walk16s
+        const int G = job.bs <= 4 ? 1 : job.bs <= 8 ? 2 : job.bs <= 16 ? 4 : 8;
+        const long long threads = nblk * job.pairs * G;
+        const unsigned grid = (unsigned)((threads + 255) / 256);
+        plan_note(ctx, 0, "k_walkq<%d,%d> %d lane(s) per block grid %u", job.bs, job.pnorm, G, grid);
+#define WALKQ(B) do { if (job.pnorm == 0) hipLaunchKernelGGL((k_walkq<B, 0>), dim3(grid), dim3(256), 0, ctx->stream, d); \
+                      else hipLaunchKernelGGL((k_walkq<B, 1>), dim3(grid), dim3(256), 0, ctx->stream, d); } while (0)
+        switch (job.bs) {
+        case 4: WALKQ(4); break;
+        case 8: WALKQ(8); break;
+        case 12: WALKQ(12); break;
+        case 20: WALKQ(20); break;
+        case 24: WALKQ(24); break;
+        case 28: WALKQ(28); break;
+        default: WALKQ(32); break;
+        }
+#undef WALKQ
     } else {
         const int px = job.bs * job.bs;
         // float32-order costs are sequential by definition: one lane per block

@@ -84,3 +84,89 @@ def test_documented_option_b_binding(golden, native, tmp_path):
     assert np.allclose(out["params"], g4["synth720_params"], rtol=1e-10, atol=1e-12)
     assert out["field"].dtype == np.int16 and np.array_equal(out["field"], g4["synth720_field"])
     assert str(out["comp_sha"]) == str(g4["synth720_comp_sha"])
+
+
+@pytest.mark.parametrize("pnorm", [0, 1])
+def test_pan240x2_every_pair_vs_oracle(native, pnorm):
+    """the elimination kernels on REAL frames -- all 50 pairs of the reference's 51 pan240 frames upscaled x2
+    (640x480, bench.py's `pan240x2` content), both norms, every pair against the C oracle; under MAE the crowded-block pass
+    (phase C2) must have run (it scores fewer patches than the first upper bounds left) and switching it off
+    (GME_SEA_QUOTA=0) must give the same fields."""
+    import bench
+    frames, H, W = bench.host_content("pan240x2", 51, 480, 720)
+    ctx = native.default_context()
+    co = c_oracle()
+    seq = native.Sequence.from_frames(ctx, frames)
+    try:
+        seq.bbme(1, 16, 16, 0, pnorm)
+        mv = seq.read_mv()
+        info = ctx.last_bbme_info()
+        assert info["plan"].startswith("k_exh_sea16p" + ("_mse" if pnorm else "") + "<3,"), info
+        want = bench.oracle_map(lambda p: co.bbme(frames[p], frames[p + 1], 16, 16, 0, pnorm), list(range(50)))
+        bad = [p for p in range(50) if not np.array_equal(mv[p], want[p])]
+        assert not bad, bad
+        if pnorm == 0:
+            assert 0 < info["surviving"] < 0.8 * info["listed"], info          # C2 ran and paid: 15.8 % -> ~10 % of the patches
+            os.environ["GME_SEA_QUOTA"] = "0"
+            try:
+                seq.invalidate_pyramids()
+                seq.bbme(1, 16, 16, 0, pnorm)
+                off = ctx.last_bbme_info()
+                assert off["surviving"] == off["listed"] > info["surviving"], (off, info)
+                assert np.array_equal(seq.read_mv(), mv)
+            finally:
+                del os.environ["GME_SEA_QUOTA"]
+        else:
+            assert info["surviving"] == info["listed"] > 0, info
+    finally:
+        seq.close()
+
+
+@pytest.mark.parametrize("proc", [1, 2, 3])
+def test_walkq_block_sizes_random_shapes(native, proc):
+    """the block sizes the reference runs besides 16 -- get_motion_field's default 4 (bbme.py:15-18), the
+    authors' BBME_BLOCK_SIZE 12 / 24 / 32 (motion.py:9, docs/presentation/main.tex:382,426,558) and the multiples of 4 between
+    them -- go through k_walkq<BS, PNORM> (whole block rows per lane, dword reads + v_alignbyte) instead of the byte-wise
+    k_walk<G>.  Shapes the grid does not divide, frames barely larger than a block, all four frame edges, pan / noise / flat /
+    mixed content, frame distances 1-3, every pair against the C oracle, bit-exact.  MSE with bs > 16 leaves float32's
+    exact-integer range (bbme.py:61-64): those calls must still take the float32-order generic path."""
+    co = c_oracle()
+    rng = np.random.default_rng(400 + proc)
+    ctx = native.default_context()
+    shapes = [(33, 47), (48, 64), (64, 96), (100, 130), (97, 143)]
+    checked = 0
+    for bs in (4, 8, 12, 20, 24, 28, 32):
+        for H, W in shapes + [(bs + 1, bs + 1), (2 * bs, 3 * bs + 3)]:
+            kind = ("pan", "noise", "flat", "mixed")[int(rng.integers(0, 4))]
+            n = int(rng.integers(3, 6))
+            if kind == "pan":
+                base = rng.integers(0, 256, (H + 80, W + 80), dtype=np.uint8)
+                frames = np.stack([base[40 + 2 * (t % 7):40 + 2 * (t % 7) + H, 40 - 3 * (t % 5):40 - 3 * (t % 5) + W] for t in range(n)])
+            elif kind == "noise":
+                frames = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+            elif kind == "flat":
+                frames = np.full((n, H, W), 77, np.uint8)
+            else:
+                base = rng.integers(0, 256, (H + 80, W + 80), dtype=np.uint8)
+                frames = np.stack([base[40 + (t % 5):40 + (t % 5) + H, 40 - 2 * (t % 6):40 - 2 * (t % 6) + W] for t in range(n)]).copy()
+                frames[:, :, :W // 2] = rng.integers(0, 256, (n, H, W // 2), dtype=np.uint8)
+            frames = np.ascontiguousarray(frames)
+            seq = native.Sequence.from_frames(ctx, frames)
+            try:
+                fd = int(rng.integers(1, min(3, n - 1) + 1))
+                sw = int(rng.choice([2, 3, 7, 16]))
+                for pn in (0, 1):
+                    seq.bbme(fd, bs, sw, proc, pn)
+                    mv = seq.read_mv()
+                    plan = ctx.last_bbme_info()["plan"]
+                    if pn == 1 and bs > 16:
+                        assert plan.startswith("k_walk<1> (float32-order costs)"), plan
+                    else:
+                        assert plan.startswith("k_walkq<%d,%d>" % (bs, pn)), plan
+                    for p in range(n - fd):
+                        want = co.bbme(frames[p], frames[p + fd], bs, sw, proc, pn)
+                        assert np.array_equal(mv[p], want), (bs, H, W, kind, fd, sw, proc, pn, p)
+                        checked += 1
+            finally:
+                seq.close()
+    assert checked >= 150

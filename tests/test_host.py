@@ -467,6 +467,29 @@ def test_committed_profiles_belong_to_these_kernels():
         assert os.path.exists(stats) and kernel.split("<")[0] in open(stats).read(), stats
 
 
+def test_benched_kernel_instances_do_not_spill():
+    """DESIGN.md said "the R = 5 body no longer spills to scratch" while the committed sources compiled to
+    215 spilled VGPRs and 192 bytes of scratch per lane.  The Makefile now keeps the compiler's own resource remarks
+    (build/*.remarks); every kernel instance bench.py's configs launch must show no VGPR spill and no scratch, and the
+    table DESIGN.md quotes must be the build's (tools/resource_table.py --check)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import resource_table
+    rows = {r["name"]: r for r in resource_table.kernels()}
+    assert rows, "no build/*.remarks: make -C global-motion-estimation_amd/csrc"
+    for name in resource_table.BENCHED:
+        hits = [r for k, r in rows.items() if k == name or (name in ("k_fit_level", "k_compensate16", "k_pyrdown_lds", "k_sqbox16") and k.startswith(name))]
+        assert hits, "no resource remarks for %s" % name
+        for r in hits:
+            assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (r["name"], r)
+    # what the launch bounds promise: 8 waves per SIMD for the R = 3 elimination kernels and the walk searches, >= 5 for the
+    # 720x480 hostile-content MSE body (round 3 claimed 5 and had 4)
+    for name, waves in (("k_exh_sea16p<3, 5, 36>", 8), ("k_exh_sea16p_mse<3, 5, 36>", 8), ("k_walk16<1>", 8), ("k_exh_redo16<3, true>", 5),
+                        ("k_exh_sea16p<5, 7, 38>", 6), ("k_exh_sea16p_mse<5, 7, 38>", 6), ("k_exh_redo16<5, true>", 4)):
+        assert rows[name]["waves"] >= waves, (name, rows[name])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "resource_table.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def test_pmc_summary_reads_only_the_newest_pass(tmp_path):
     """tools/pmc_summary.py: gpurun merges a call's files INTO the local gpurun_out/, so a pass directory re-used by a later
     profile run also holds the CSVs of earlier builds.  Only the newest CSV of each pass directory may enter the summary
