@@ -75,6 +75,8 @@ _SIGNATURES = {
     "gme_seq_gme_begin_fit": (_i, [_vp, _i, _i, _i, _i, ctypes.c_double, _c_f32p, _c_f64p]),
     "gme_seq_gme_read_stage": (_i, [_vp, _i, _i, _c_i32p, _c_i16p, _c_u8p, _c_i64p]),
     "gme_seq_compensate": (_i, [_vp, _i, _i, _c_f64p, _c_i64p]),
+    "gme_solve_fit_sums": (_i, [_vp, _c_f64p, _i, _i, _i, _i, _c_f64p, _c_i32p]),
+    "gme_seq_gme_device_solve": (_i, [_vp, _i, _i, _i, _i, ctypes.c_double, _c_f64p, _c_i64p, _c_i32p]),
     "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
     "gme_seq_set_split_phase": (_i, [_vp, _i]),
     "gme_seq_wait": (_i, [_vp]),
@@ -228,6 +230,15 @@ class Context:
         _check(self.lib.gme_last_bbme_info(self.handle, plan, 192, ctypes.byref(n), ctypes.byref(k), ctypes.byref(r)), self.lib)
         _check(self.lib.gme_last_bbme_listed(self.handle, ctypes.byref(l)), self.lib)
         return {"plan": plan.value.decode(), "patches": n.value, "surviving": k.value, "listed": l.value, "redo_tiles": r.value}
+
+    def solve_fit_sums(self, sums, h, w, project=False):
+        """gme_solve_fit_sums: float64[P, 15] normal-equation sums -> (params float64[P, 6], flags int32[P])."""
+        sums = np.ascontiguousarray(np.asarray(sums, dtype=np.float64).reshape(-1, 15))
+        params = np.empty((len(sums), 6), np.float64)
+        flags = np.empty(len(sums), np.int32)
+        _check(self.lib.gme_solve_fit_sums(self.handle, _p(sums, _c_f64p), len(sums), int(bool(project)), int(h), int(w),
+                                           _p(params, _c_f64p), _p(flags, _c_i32p)), self.lib)
+        return params, flags
 
     def timer_start(self):
         _check(self.lib.gme_timer_start(self.handle), self.lib)
@@ -518,6 +529,19 @@ class Sequence:
         _check(self.lib.gme_seq_compensate(self.handle, frame_distance, block_size, _p(p, _c_f64p), _p(sse, _c_i64p)),
                self.lib)
         return sse
+
+    def gme_device_solve(self, frame_distance, bbme_block_size, outlier_fraction, procedure=3, search_window=2):
+        """The whole estimate + compensation with the 3x3 solves on the device (gme_seq_gme_device_solve): one round trip
+        -> (params float64[P, 6], sse int64[P], flags int32[P]); pairs with a non-zero flag must be redone by the staged calls."""
+        pairs = self.N - frame_distance
+        bbme_block_size = _block_size(bbme_block_size)
+        params = self._buffer("dev_params", (max(pairs, 0), 6), np.float64)
+        sse = self._buffer("dev_sse", (max(pairs, 0),), np.int64)
+        flags = self._buffer("dev_flags", (max(pairs, 0),), np.int32)
+        _check(self.lib.gme_seq_gme_device_solve(self.handle, frame_distance, bbme_block_size, procedure, search_window,
+                                                 float(outlier_fraction), _p(params, _c_f64p), _p(sse, _c_i64p), _p(flags, _c_i32p)), self.lib)
+        self._gme = (frame_distance, bbme_block_size, pairs)
+        return params, sse, flags
 
     def read_compensated(self, pair):
         out = np.empty((self.H, self.W), dtype=np.uint8)

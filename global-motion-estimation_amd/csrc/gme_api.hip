@@ -484,6 +484,7 @@ extern "C" void gme_seq_destroy(gme_seq* s)
     for (int l = 0; l < 3; ++l) if (s->sqbox[l]) hipFree(s->sqbox[l]);
     if (s->params0) hipFree(s->params0);
     if (s->params_in) hipFree(s->params_in);
+    if (s->solve_flags) hipFree(s->solve_flags);
     if (s->sse) hipFree(s->sse);
     if (s->comp_params) hipFree(s->comp_params);
     if (s->synth_canvas) hipFree(s->synth_canvas);
@@ -1053,8 +1054,10 @@ static int gme_begin_common(gme_seq* s, int fd, int bbme_bs, int procedure, int 
         }
         if (s->params0) hipFree(s->params0);
         if (s->params_in) hipFree(s->params_in);
-        s->params0 = nullptr; s->params_in = nullptr;
+        if (s->solve_flags) hipFree(s->solve_flags);
+        s->params0 = nullptr; s->params_in = nullptr; s->solve_flags = nullptr;
         if (hipMalloc((void**)&s->params0, (size_t)cap_pairs * 6 * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&s->solve_flags, (size_t)(cap_pairs > 0 ? cap_pairs : 1) * sizeof(int32_t)) != hipSuccess ||
             hipMalloc((void**)&s->params_in, (size_t)cap_pairs * 6 * sizeof(double)) != hipSuccess) {
             gme_set_error("out of device memory (parameters)");
             return GME_ERR_NOMEM;
@@ -1208,6 +1211,7 @@ static int fit_level_launch(gme_seq* s, int level, const double* dparams, double
     int rc = launch_fit_level(ctx, f->gt, pairs, f->h, f->w, dparams, drop, s->level[level].H, s->level[level].W, f->model, f->mask,
                               f->diff, f->thr, f->sums, f->list);
     if (rc) return rc;
+    if (!sums_out) return GME_OK;                          // gme_seq_gme_device_solve: the sums stay on the device
     rc = copy_small(ctx, sums_out, f->sums, (size_t)pairs * 15 * sizeof(double), hipMemcpyDeviceToHost, s->split_phase);
     if (rc) return rc;
     if (s->split_phase) GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream));
@@ -1242,6 +1246,26 @@ extern "C" int gme_seq_gme_read_stage(gme_seq* s, int level, int pair, int32_t* 
     return rc;
 }
 
+static int ensure_comp(gme_seq* s, int fd, int pairs)
+{
+    gme_ctx* ctx = s->ctx;
+    if (!s->comp.ptr || s->comp.count < pairs) {
+        const int cap_pairs = s->N_cap - fd > pairs ? s->N_cap - fd : pairs;
+        plane_free(&s->comp);
+        int rc = plane_alloc(ctx, &s->comp, cap_pairs, s->H, s->W);
+        if (rc) return rc;
+        if (s->sse) hipFree(s->sse);
+        if (s->comp_params) hipFree(s->comp_params);
+        s->sse = nullptr; s->comp_params = nullptr;
+        if (hipMalloc((void**)&s->sse, (size_t)cap_pairs * sizeof(unsigned long long)) != hipSuccess ||
+            hipMalloc((void**)&s->comp_params, (size_t)cap_pairs * 6 * sizeof(double)) != hipSuccess) {
+            gme_set_error("out of device memory");
+            return GME_ERR_NOMEM;
+        }
+    }
+    return GME_OK;
+}
+
 extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* params, int64_t* sse_out)
 {
     GME_REQUIRE(s != nullptr && params != nullptr, GME_ERR_ARG, "gme_seq_compensate: null pointer");
@@ -1253,20 +1277,8 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
     GME_REQUIRE(bs >= 1, GME_ERR_ARG, "block_size %d", bs);
     const int h = s->H / bs, w = s->W / bs;
     GME_REQUIRE(h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bs, s->H, s->W);
-    if (!s->comp.ptr || s->comp.count < pairs) {
-        const int cap_pairs = s->N_cap - fd > pairs ? s->N_cap - fd : pairs;
-        plane_free(&s->comp);
-        rc = plane_alloc(ctx, &s->comp, cap_pairs, s->H, s->W);
-        if (rc) return rc;
-        if (s->sse) hipFree(s->sse);
-        if (s->comp_params) hipFree(s->comp_params);
-        s->sse = nullptr; s->comp_params = nullptr;
-        if (hipMalloc((void**)&s->sse, (size_t)cap_pairs * sizeof(unsigned long long)) != hipSuccess ||
-            hipMalloc((void**)&s->comp_params, (size_t)cap_pairs * 6 * sizeof(double)) != hipSuccess) {
-            gme_set_error("out of device memory");
-            return GME_ERR_NOMEM;
-        }
-    }
+    rc = ensure_comp(s, fd, pairs);
+    if (rc) return rc;
     rc = copy_small(ctx, s->comp_params, params, (size_t)pairs * 6 * sizeof(double), hipMemcpyHostToDevice, s->split_phase);
     if (rc) return rc;
     const Plane& p = s->level[2];
@@ -1280,6 +1292,82 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
         return ctx_finish(ctx);
     }
     return GME_OK;
+}
+
+// The device solve on its own (what gme_seq_gme_device_solve runs between its stages), for callers and tests that hold
+// normal-equation sums: sums[P][15] = F | Sx | Sy -> params_out[P][6] (first components doubled if `project`,
+// motion.py:191-207) and flags_out[P]: bit 1 where a displacement of the h x w model field of those parameters lies within
+// 1e-9 of a rounding tie, bit 4 for a singular system.
+extern "C" int gme_solve_fit_sums(gme_ctx* ctx, const double* sums, int pairs, int project, int h, int w, double* params_out,
+                                  int32_t* flags_out)
+{
+    GME_ENTER(ctx);
+    GME_REQUIRE(sums != nullptr && params_out != nullptr && flags_out != nullptr && pairs >= 0 && h >= 0 && w >= 0, GME_ERR_ARG,
+                "gme_solve_fit_sums: bad arguments");
+    if (pairs == 0) return GME_OK;
+    void* buf = nullptr;
+    const size_t b_sums = (size_t)pairs * 15 * sizeof(double), b_par = (size_t)pairs * 6 * sizeof(double), b_fl = (size_t)pairs * sizeof(int32_t);
+    int rc = ctx_scratch(ctx, b_sums + b_par + b_fl, &buf);
+    if (rc) return rc;
+    double* d_sums = (double*)buf;
+    double* d_par = (double*)((char*)buf + b_sums);
+    int32_t* d_fl = (int32_t*)((char*)buf + b_sums + b_par);
+    GME_HIP_TRY(hipMemcpyAsync(d_sums, sums, b_sums, hipMemcpyHostToDevice, ctx->stream));
+    GME_HIP_TRY(hipMemsetAsync(d_fl, 0, b_fl, ctx->stream));
+    rc = launch_solve3(ctx, d_sums, pairs, project, h, w, d_par, d_fl, 1);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemcpyAsync(params_out, d_par, b_par, hipMemcpyDeviceToHost, ctx->stream));
+    GME_HIP_TRY(hipMemcpyAsync(flags_out, d_fl, b_fl, hipMemcpyDeviceToHost, ctx->stream));
+    return ctx_finish(ctx);
+}
+
+// motion.global_motion_estimation + get_motion_field_affine + compensate_frame + the squared error of results.py:50-59,109
+// for every pair in ONE call with ONE host round trip: the 3x3 solves of motion.py:262-264,280-282 run on the device
+// (k_solve3, gme_kernels.hip).  Opt-in (the package uses it under GME_DEVICE_SOLVE=1): LAPACK's last bits are not
+// reproduced, parameters are within rtol 1e-10 of the host path's; flags_out[p] != 0 names the pairs the caller must
+// redo through the host path (a model displacement within 1e-9 of a rounding tie: bit 1 at level 2, bit 2 in the final
+// field; bit 4: a singular system, numpy.linalg.LinAlgError upstream) -- for all other pairs model fields, masks,
+// compensated frames and squared errors are bit-equal to the staged calls'.  Split-phase like them.
+extern "C" int gme_seq_gme_device_solve(gme_seq* s, int fd, int bbme_bs, int procedure, int sw, double outlier_fraction,
+                                        double* params_out, int64_t* sse_out, int32_t* flags_out)
+{
+    GME_REQUIRE(s != nullptr && params_out != nullptr && flags_out != nullptr, GME_ERR_ARG, "gme_seq_gme_device_solve: null pointer");
+    gme_ctx* ctx = s->ctx;
+    GME_ENTER(ctx);
+    int rc = gme_begin_common(s, fd, bbme_bs, procedure, sw);
+    if (rc) return rc;
+    const int pairs = s->gme_pairs;
+    const int h = s->H / bbme_bs, w = s->W / bbme_bs;
+    GME_REQUIRE(h > 0 && w > 0, GME_ERR_GEOMETRY, "block_size %d does not fit a %d x %d frame", bbme_bs, s->H, s->W);
+    rc = ensure_comp(s, fd, pairs);
+    if (rc) return rc;
+    GME_HIP_TRY(hipMemsetAsync(s->solve_flags, 0, (size_t)(pairs > 0 ? pairs : 1) * sizeof(int32_t), ctx->stream));
+    rc = launch_project_first(ctx, s->params0, pairs, s->params_in);
+    if (rc) return rc;
+    rc = gme_level_bbme(s, 1);
+    if (rc) return rc;
+    rc = gme_level_bbme(s, 2);                             // independent of the parameters: queued ahead of the level-1 fit
+    if (rc) return rc;
+    rc = fit_level_launch(s, 1, s->params_in, outlier_fraction, nullptr);
+    if (rc) return rc;
+    // level-1 solution, projected (motion.py:191-207), used for the level-2 model field: flag bit 1 where that rounds near a tie
+    rc = launch_solve3(ctx, s->fit[1].sums, pairs, 1, s->fit[2].h, s->fit[2].w, s->params_in, s->solve_flags, 1);
+    if (rc) return rc;
+    rc = fit_level_launch(s, 2, s->params_in, outlier_fraction, nullptr);
+    if (rc) return rc;
+    rc = launch_solve3(ctx, s->fit[2].sums, pairs, 0, h, w, s->comp_params, s->solve_flags, 2);
+    if (rc) return rc;
+    const Plane& p = s->level[2];
+    rc = launch_compensate(ctx, p.at(0), p.stride, pairs, s->H, s->W, p.pitch, nullptr, s->comp_params, h, w, s->comp.ptr,
+                           s->comp.stride, s->comp.pitch, p.at(fd), p.stride, s->sse);
+    if (rc) return rc;
+    rc = copy_small(ctx, params_out, s->comp_params, (size_t)pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, s->split_phase);
+    if (rc) return rc;
+    if (sse_out) { rc = copy_small(ctx, sse_out, s->sse, (size_t)pairs * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->split_phase); if (rc) return rc; }
+    rc = copy_small(ctx, flags_out, s->solve_flags, (size_t)pairs * sizeof(int32_t), hipMemcpyDeviceToHost, s->split_phase);
+    if (rc) return rc;
+    if (s->split_phase) { GME_HIP_TRY(hipEventRecord(s->ready, ctx->stream)); return GME_OK; }
+    return ctx_finish(ctx);
 }
 
 extern "C" int gme_seq_read_compensated(gme_seq* s, int pair, uint8_t* out)

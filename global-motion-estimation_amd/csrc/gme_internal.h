@@ -113,6 +113,7 @@ struct gme_seq {
     size_t mv_params_bytes = 0;
     float* params0 = nullptr;     // [P][6]
     double* params_in = nullptr;  // [P][6]
+    int32_t* solve_flags = nullptr;      // [P] gme_seq_gme_device_solve: pairs whose device solve must be redone on the host
     size_t gme_alloc_pairs = 0;
     // compensation
     Plane comp;                   // [P] compensated frames
@@ -220,6 +221,7 @@ int launch_fit_level(gme_ctx* ctx, const int32_t* gt, int pairs, int h, int w, c
                      int drop_count, int level_H, int level_W, int16_t* model, uint8_t* mask,
                      int32_t* diff, int32_t* thr, double* sums, void* list);
 int launch_affine_field(gme_ctx* ctx, const double* params, int pairs, int h, int w, int16_t* out);
+int launch_solve3(gme_ctx* ctx, const double* sums, int pairs, int project, int h, int w, double* params_out, int32_t* flags, int flag_bit);
 int launch_mv_summary(gme_ctx* ctx, const int32_t* mf, int pairs, int n_blocks, double* rows);
 int launch_compensate(gme_ctx* ctx, const uint8_t* frames, int64_t frame_stride, int pairs, int H,
                       int W, int pitch, const int32_t* mf32, const double* params, int h, int w,

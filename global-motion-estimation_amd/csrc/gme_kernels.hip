@@ -341,6 +341,72 @@ __device__ __forceinline__ int16_t model_component(double p0, double p1, double 
     return (int16_t)(long long)rint(d);      // round-half-even, int16 store wraps
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in (GME_DEVICE_SOLVE=1, gme_seq_gme_device_solve): the two 3x3 solves of motion.py:262-264,280-282 on the device, so
+// that a whole estimate is ONE host round trip instead of three.  The reference inverts F with LAPACK (np.linalg.inv); a
+// device solve cannot reproduce LAPACK's last bits (builds already differ by ~1e-13 among themselves), so:
+//   * parameters are promised to rtol 1e-10 only (the tolerance every parity test uses for them anyway);
+//   * everything DOWNSTREAM of a solve must stay bit-equal -- model fields, masks, compensated frames.  Those depend on
+//     the parameters only through round-half-even of the model displacements (model_component below), so the kernel
+//     evaluates the field the parameters will be used for and raises the pair's flag when any displacement lies within
+//     `margin` (1e-9) of k + 0.5: such a pair -- and a singular system, for which upstream raises LinAlgError -- is
+//     redone through the host path by the caller.  Elsewhere a 1e-10 relative parameter error cannot move a rounding.
+// One workgroup per pair: thread 0 solves (Gaussian elimination with partial pivoting, every product and sum rounded
+// separately), all threads scan the field.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool solve3(const double* F, const double* S, double* x)
+{
+    double a[3][4];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) a[r][c] = F[3 * r + c]; a[r][3] = S[r]; }
+    for (int k = 0; k < 3; ++k) {
+        int piv = k;
+        for (int r = k + 1; r < 3; ++r) if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
+        if (a[piv][k] == 0.0) return false;
+        if (piv != k) for (int c = 0; c < 4; ++c) { const double t = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = t; }
+        for (int r = k + 1; r < 3; ++r) {
+            const double m = __ddiv_rn(a[r][k], a[k][k]);
+            for (int c = k; c < 4; ++c) a[r][c] = __dsub_rn(a[r][c], __dmul_rn(m, a[k][c]));
+        }
+    }
+    for (int k = 2; k >= 0; --k) {
+        double t = a[k][3];
+        for (int c = k + 1; c < 3; ++c) t = __dsub_rn(t, __dmul_rn(a[k][c], x[c]));
+        x[k] = __ddiv_rn(t, a[k][k]);
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_solve3(const double* sums, int pairs, int project, int h, int w, double margin,
+                                                double* params_out, int32_t* flags, int flag_bit)
+{
+    __shared__ double p[6];
+    __shared__ int bad;
+    const int pair = blockIdx.x;
+    if (threadIdx.x == 0) {
+        const double* s = sums + (long long)pair * 15;
+        double ax[3] = { 0, 0, 0 }, ay[3] = { 0, 0, 0 };
+        bad = (solve3(s, s + 9, ax) && solve3(s, s + 12, ay)) ? 0 : 4;           // 4: singular system (numpy.linalg.LinAlgError upstream)
+        if (project) { ax[0] = __dmul_rn(ax[0], 2.0); ay[0] = __dmul_rn(ay[0], 2.0); }     // motion.py:191-207
+        p[0] = ax[0]; p[1] = ax[1]; p[2] = ax[2]; p[3] = ay[0]; p[4] = ay[1]; p[5] = ay[2];
+        for (int k = 0; k < 6; ++k) params_out[(long long)pair * 6 + k] = p[k];
+    }
+    __syncthreads();
+    int near_half = 0;
+    for (int b = threadIdx.x; b < h * w; b += blockDim.x) {
+        const int i = b / w, j = b - i * w;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double d = __dadd_rn(__dadd_rn(p[3 * c], __dmul_rn(p[3 * c + 2], (double)j)), __dmul_rn(p[3 * c + 1], (double)i));
+            const double fr = d - floor(d);
+            if (fabs(fr - 0.5) < margin || !(fabs(d) < 30000.0)) near_half = 1;    // (also: outside int16's comfortable range, NaN)
+        }
+    }
+    if (near_half) atomicOr(&bad, flag_bit);
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) atomicOr(flags + pair, bad);
+}
+
+
 __global__ void __launch_bounds__(256) k_affine_field(const double* params, int h, int w, int16_t* out)
 {
     const int n = h * w;
@@ -903,6 +969,14 @@ int launch_sse(gme_ctx* ctx, const uint8_t* a, int64_t a_stride, int a_pitch, co
         hipLaunchKernelGGL(k_sse, grid, dim3(256), 0, ctx->stream, a + (int64_t)first * a_stride, (long long)a_stride, a_pitch,
                            b + (int64_t)first * b_stride, (long long)b_stride, b_pitch, H, W, sse + first);
     }
+    GME_HIP_TRY(hipGetLastError());
+    return GME_OK;
+}
+
+int launch_solve3(gme_ctx* ctx, const double* sums, int pairs, int project, int h, int w, double* params_out, int32_t* flags, int flag_bit)
+{
+    if (pairs == 0) return GME_OK;
+    hipLaunchKernelGGL(k_solve3, dim3((unsigned)pairs), dim3(256), 0, ctx->stream, sums, pairs, project, h, w, 1e-9, params_out, flags, flag_bit);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
 }

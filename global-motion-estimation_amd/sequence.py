@@ -474,6 +474,11 @@ class ShardedSequence:
         if not self.lanes:
             return np.zeros((0, 6)), np.zeros(0)
 
+        if os.environ.get("GME_DEVICE_SOLVE") == "1":
+            got = self._device_solved(procedure, search_window, exact_psnr)
+            if got is not None:
+                return got                        # else: a pair sat on a rounding tie (or was singular): the host path below
+
         if self.interleave and len(self.lanes) > 1:
             return self._interleaved(procedure, search_window, True, exact_psnr)
 
@@ -483,6 +488,34 @@ class ShardedSequence:
             return p, lane.seq.compensate(self.fd, int(motion.BBME_BLOCK_SIZE), p)[:n]
         parts = self._each(run)
         return np.concatenate([p for p, _ in parts], axis=0), self._psnr(np.concatenate([s for _, s in parts]), exact_psnr)
+
+    def _device_solved(self, procedure, search_window, exact_psnr=False):
+        """estimate_and_compensate() with the 3x3 solves on the device (GME_DEVICE_SOLVE=1, gme_seq_gme_device_solve): every
+        lane's whole estimate is queued in one call, one wait per lane.  Parameters are within rtol 1e-10 of the host
+        path's (LAPACK's last bits are not reproduced); model fields, masks, compensated frames and PSNR are bit-equal to
+        it -- unless the library flags a pair (a model displacement within 1e-9 of a rounding tie, or a singular system):
+        then nothing is returned and the caller runs the host path, which also raises upstream's LinAlgError."""
+        frac = float(motion.MOTION_VECTOR_ERROR_THRESHOLD_PERCENTAGE)
+        bs = int(motion.BBME_BLOCK_SIZE)
+        lanes = self.lanes
+        for lane in lanes:
+            lane.seq.set_split_phase(True)
+        try:
+            pending = [lane.seq.gme_device_solve(self.fd, bs, frac, procedure, search_window) for lane in lanes]
+            params, sse, clean = [], [], True
+            for lane, (p, e, f) in zip(lanes, pending):
+                lane.seq.wait()
+                n = lane.hi - lane.lo
+                clean = clean and not np.any(f[:n])
+                params.append(np.array(p[:n]))
+                sse.append(np.array(e[:n]))
+                lane.ctx.sync()                   # drains the stream and reports a walk that overran its guard
+        finally:
+            for lane in lanes:
+                lane.seq.set_split_phase(False)
+        if not clean:
+            return None
+        return np.concatenate(params, axis=0), self._psnr(np.concatenate(sse), exact_psnr)
 
     def _interleaved(self, procedure, search_window, compensate, exact_psnr=False):
         """estimate() / estimate_and_compensate() for several ranges from one host thread: every stage is queued on

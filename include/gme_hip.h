@@ -189,6 +189,21 @@ GME_API int gme_seq_gme_read_stage(gme_seq *seq, int level, int pair, int32_t *g
 GME_API int gme_seq_compensate(gme_seq *seq, int frame_distance, int block_size, const double *params,
                        int64_t *sse_out);
 GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
+/* Opt-in one-call form of begin_fit -> solve -> fit(2) -> solve -> compensate with the two 3x3 solves of
+ * motion.py:262-264,280-282 on the device: one host round trip per estimate instead of three.  LAPACK's last bits are not
+ * reproduced: params_out[P][6] is within rtol 1e-10 of the staged path's (motion.py:109-136); model fields, masks,
+ * compensated frames (results.py:52-59) and sse_out[P] (may be NULL) are bit-equal to it for every pair whose flags_out[p]
+ * is 0.  A non-zero flag -- bit 1 / 2: a model displacement within 1e-9 of a rounding tie at level 2 / in the final field;
+ * bit 4: a singular system (numpy.linalg.LinAlgError upstream, motion.py:262) -- tells the caller to redo that pair through
+ * the staged calls.  Split-phase like them (gme_seq_set_split_phase). */
+/* The device solve by itself: sums[P][15] = F (9, row-major) | Sx | Sy -> params_out[P][6] (motion.py:262-286; first
+ * components doubled if `project`, motion.py:191-207) and flags_out[P] (bit 1: a displacement of the h x w model field of
+ * those parameters within 1e-9 of a rounding tie, motion.py:139-157; bit 4: singular).  Host pointers. */
+GME_API int gme_solve_fit_sums(gme_ctx *ctx, const double *sums, int pairs, int project, int h, int w, double *params_out,
+                       int32_t *flags_out);
+GME_API int gme_seq_gme_device_solve(gme_seq *seq, int frame_distance, int bbme_block_size, int procedure, int search_window,
+                             double outlier_fraction, double *params_out, int64_t *sse_out, int32_t *flags_out);
+
 
 /* Split-phase form of the three calls above (no counterpart in the reference, whose stages are plain function calls,
  * motion.py:109-136; this is how ONE host thread keeps several streams busy).  With the switch on,
