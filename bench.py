@@ -62,6 +62,9 @@ CONFIGS = {
                 "diamond-search GME + compensate + PSNR, RCCL all-gather of per-pair parameters (BASELINE configs[4])"),
     "gme1080": (1080, 1920, 16, 2, -1, 1, 2000, "1920x1080 synthetic sequence, diamond-search GME + compensate, "
                 "BASELINE configs[4] per-GPU shard"),
+    "gme720dev": (480, 720, 16, 2, -1, 1, 1234, "720x480 full multiscale affine GME + compensate + PSNR (BASELINE configs[2]) with the OPT-IN "
+                  "device solve (GME_DEVICE_SOLVE=1: 3x3 solves on the device, one host round trip per estimate; parameters within "
+                  "rtol 1e-10, everything downstream bit-equal or flagged back to the host path)"),
     # the block sizes the reference itself runs besides 16
     "tss_bs4sw2": (480, 720, 4, 2, 1, 1, 1234, "720x480 synthetic luma, bs=4 sw=2 three-step search MSE: bbme.get_motion_field's own "
                    "defaults (bbme.py:15-18)"),
@@ -70,7 +73,7 @@ CONFIGS = {
                            "(docs/presentation/main.tex:382; golden g9)"),
 }
 # per-config extras: frame content uploaded from the host instead of the synthetic generator, frame distance
-EXTRA = {"gme_pan240_bs12fd5": {"content": "pan240seq", "fd": 5}}
+EXTRA = {"gme_pan240_bs12fd5": {"content": "pan240seq", "fd": 5}, "gme720dev": {"env": {"GME_DEVICE_SOLVE": "1"}, "streams": 2}}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # measured on MI355X (tools/microbench/valu_rates2.hip, profiles/r01_valu_rates.txt):
 # v_qsad_pk_u16_u8 issues one wave-instruction (64 lanes x 16 byte-abs-diffs) per ~16.3
@@ -80,11 +83,11 @@ PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per b
 # rough C-oracle seconds per pair (one core), to size the parity sample
 ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080mse": 1.8, "dia720": 0.01,
                      "dia720mse": 0.01, "tss720": 0.01, "tdl720": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15,
-                     "gme1080exh": 2.1, "tss_bs4sw2": 0.02, "gme_pan240_bs12fd5": 0.01}
+                     "gme1080exh": 2.1, "tss_bs4sw2": 0.02, "gme_pan240_bs12fd5": 0.01, "gme720dev": 0.03}
 # the default line's "secondary" block: (config, pairs per step, steps, warmup, wall seconds of C-oracle parity on
 # ORACLE_THREADS threads, pairs the parity gate checks at least).  seq1080 = BASELINE configs[4] at N = 1: the whole
 # 2000-frame video, with the world-1 RCCL all-gather (gme_shard_gather) inside every step.
-SECONDARY = [("gme720", 2048, 20, 3, 1.0, 8), ("exh720mse", 2048, 12, 3, 1.0, 8), ("dia720mse", 2048, 20, 3, 0.5, 8),
+SECONDARY = [("gme720", 2048, 20, 3, 1.0, 8), ("gme720dev", 2048, 20, 3, 1.0, 8), ("exh720mse", 2048, 12, 3, 1.0, 8), ("dia720mse", 2048, 20, 3, 0.5, 8),
              ("tss720", 2048, 20, 3, 0.5, 8), ("tdl720", 2048, 20, 3, 0.5, 8),
              ("tss_bs4sw2", 2048, 20, 3, 0.5, 8), ("gme_pan240_bs12fd5", 2048, 20, 3, 0.5, 8),
              ("exh1080mse", 512, 8, 2, 3.0, 8), ("gme1080exh", 512, 8, 2, 3.5, 8), ("seq1080", None, 8, 2, 2.0, 8)]
@@ -465,6 +468,8 @@ def measure(opt, ctx, comm, rank, world):
     fd = extra.get("fd", 1)
     B = opt.pairs if opt.pairs is not None else DEFAULT_PAIRS
     distributed = comm.kind != "none"
+    env_before = {k: os.environ.get(k) for k in extra.get("env", {})}
+    os.environ.update(extra.get("env", {}))
     import motion as _motion
     bs_before = _motion.BBME_BLOCK_SIZE
     if gme:
@@ -477,7 +482,7 @@ def measure(opt, ctx, comm, rank, world):
     # gme720 1 stream 499-513 k pairs/s; 2 / 3 / 4 interleaved streams 582 / 588 / 596 k; with a host thread per
     # stream (GME_BENCH_INTERLEAVE=0) 2 / 3 / 4 streams gave 452-471 / 499 / 385-407 k on the same boxes.
     # Round 3, final kernels, same box, four rounds: 2 / 3 / 4 / 6 ranges 619 / 647 / 655 / 634 k (means) -> 4.
-    streams = int(os.environ.get("GME_BENCH_STREAMS", "1" if proc == -2 else "4"))
+    streams = int(os.environ.get("GME_BENCH_STREAMS", str(extra.get("streams", 1 if proc == -2 else 4))))
     interleave = os.environ.get("GME_BENCH_INTERLEAVE", "1") == "1"      # one host thread over all streams (split-phase calls)
     shard = seq = None
     if proc == -3:
@@ -604,6 +609,11 @@ def measure(opt, ctx, comm, rank, world):
 
     def release():
         _motion.BBME_BLOCK_SIZE = bs_before
+        for k, v in env_before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         if seq is not None:
             seq.close()
         if shard is not None:
