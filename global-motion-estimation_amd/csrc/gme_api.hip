@@ -505,7 +505,9 @@ extern "C" int gme_seq_set_split_phase(gme_seq* s, int on)
 {
     GME_REQUIRE(s != nullptr, GME_ERR_ARG, "null sequence");
     GME_ENTER(s->ctx);
-    if (on && !s->ready) GME_HIP_TRY(hipEventCreateWithFlags(&s->ready, hipEventDisableTiming));
+    // release-to-system: the results behind this event are written by a kernel into host memory the CALLER chose; whatever
+    // its coherence (hipHostMallocNonCoherent, hipHostRegister'ed, HIP_HOST_COHERENT=0), they are visible once it fires
+    if (on && !s->ready) GME_HIP_TRY(hipEventCreateWithFlags(&s->ready, hipEventDisableTiming | hipEventReleaseToSystem));
     s->split_phase = on != 0;
     return GME_OK;
 }

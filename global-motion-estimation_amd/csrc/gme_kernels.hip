@@ -891,6 +891,11 @@ int launch_project_first(gme_ctx* ctx, const float* params0, int pairs, double* 
 int launch_mv_summary(gme_ctx* ctx, const int32_t* mf, int pairs, int n_blocks, double* rows)
 {
     if (pairs == 0) return GME_OK;
+    // 64 KiB of histogram + 32 bytes of static LDS per workgroup: fine on gfx950 (160 KiB), beyond the 64 KiB of other gfx9
+    // parts the Makefile's ARCH could name -- refuse clearly instead of failing at launch
+    GME_REQUIRE((size_t)ctx->prop.sharedMemPerBlock >= SUMMARY_BINS * sizeof(unsigned int) + 64, GME_ERR_ARG,
+                "gme_seq_mv_summary needs %zu bytes of LDS per workgroup, this device offers %zu",
+                SUMMARY_BINS * sizeof(unsigned int) + 64, (size_t)ctx->prop.sharedMemPerBlock);
     hipLaunchKernelGGL(k_mv_summary, dim3(pairs), dim3(256), SUMMARY_BINS * sizeof(unsigned int), ctx->stream, mf, n_blocks, rows);
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;

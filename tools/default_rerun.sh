@@ -1,6 +1,7 @@
 # usage (GPU box): bash tools/default_rerun.sh <tag>   -- the default bench line alone (with its secondary block), into gpurun_out/<tag>/
-TAG=${1:-r03_final}; O=gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r04_final}; O=gpurun_out/$TAG
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $O
 t0=$(date +%s)
 timeout -k 10 600 python3 bench.py > $O/${TAG}_default_bench.json 2> $O/default_bench.err || { echo "default bench failed"; tail -5 $O/default_bench.err; }
 echo "default bench: $(( $(date +%s) - t0 )) s"
