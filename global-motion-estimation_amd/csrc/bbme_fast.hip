@@ -487,6 +487,8 @@ __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch
 // write-bound kernel at 3.4 TB/s with nobody to cover its latencies); the row that leaves the window, h(y - 1), is now
 // recomputed from a second read of that source row (16 rows back in the same thread's walk: L2 hits) -- twice the vector
 // work of a kernel that was 26 % VALU-busy, a quarter of the registers.
+// (Round 4 tried the ring in LDS -- 16 x 16 bytes per thread, 64 KiB per workgroup, minimum traffic: 2 waves per SIMD are too
+// few for a streaming kernel, exhaustive MSE 328 k -> 291 k pairs/s, same box.)
 __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long src_stride, int H, int W, int pitch,
                                                  uint32_t* dst, long long dst_stride)
 {

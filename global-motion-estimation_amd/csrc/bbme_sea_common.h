@@ -178,12 +178,12 @@ __device__ __forceinline__ void stage_window(const SeaDev& d, uint32_t* win, con
 // registers: S8(y) = S8(y-1) + r8(y+7) - r8(y-1).  s8[y][sq] = packed S8(y, 4sq .. 4sq+3).
 // CH = s8_rows / 8 is a template parameter so that the ring indices and the warm-up are resolved
 // at compile time (a run-time row count cost 5 % of the whole search in guards).
-template <int CH>
+template <int CH, int NCH = 8>
 __device__ __forceinline__ void box_sums8_ch(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
 {
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     const int XQ = d.xq;
-    for (int it = tid; it < 8 * XQ; it += blockDim.x) {
+    for (int it = tid; it < NCH * XQ; it += blockDim.x) {
         const int ch = div_small(it, d.magic_xq), sq = it - ch * XQ;
         int pi = (ch * CH) * d.pitch_dw + sq, oi = (ch * CH) * XQ + sq;     // running offsets: adds, no r * pitch multiplies
         u16x4 ring[8], sum = { 0, 0, 0, 0 };
@@ -207,11 +207,20 @@ __device__ __forceinline__ void box_sums8_ch(const SeaDev& d, const uint32_t* wi
 }
 
 // s8_rows = 16R + 8 + 16 (tr - 1) is a multiple of 8 for every tile height: 8 chunks of 2R + 2 tr - 1 rows
+// (SEA_BOX_CHUNKS = 4: four chunks of twice the rows for two-row tiles -- 7 warm-up rows per chunk are 44 % of a 9-row
+// chunk's work and 28 % of an 18-row one's, but half as many lanes share it; A/B in DESIGN.md)
+#ifndef SEA_BOX_CHUNKS
+#define SEA_BOX_CHUNKS 8
+#endif
 template <int R>
 __device__ __forceinline__ void box_sums8(const SeaDev& d, const uint32_t* win, uint64_t* s8, int tid)
 {
     if (d.tr == 1) box_sums8_ch<2 * R + 1>(d, win, s8, tid);
-    else if (d.tr == 2) box_sums8_ch<2 * R + 3>(d, win, s8, tid);
+    else if (d.tr == 2) {
+        constexpr int ROWS = 16 * R + 24;                  // s8_rows of a two-row tile
+        if (SEA_BOX_CHUNKS != 8 && ROWS % SEA_BOX_CHUNKS == 0) box_sums8_ch<ROWS / SEA_BOX_CHUNKS, SEA_BOX_CHUNKS>(d, win, s8, tid);
+        else box_sums8_ch<2 * R + 3>(d, win, s8, tid);
+    }
     else box_sums8_ch<2 * R + 7>(d, win, s8, tid);
 }
 
