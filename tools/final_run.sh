@@ -50,7 +50,7 @@ for f in ("gloo2", "rccl1"):
         print(f, "failed", e)
 PY
   bash tools/gloo2_seq1080.sh $O/gloo2_seq1080 2>&1 | head -1; cp $O/gloo2_seq1080/gloo2_seq1080_bench.json $O/${TAG}_gloo2_seq1080_bench.json 2>/dev/null
-  bash tools/rccl_dup_rehearsal.sh $O/rccl_dup 2>&1 | head -2
+  bash tools/rccl_dup_rehearsal.sh $O/rccl_dup 2>&1 | head -14
   bash tools/scale_run.sh exh720 20 3 $O/scale 2>&1 | tail -3
 elif [ "$PART" = benches ]; then
   for c in exh720mse exh1080 exh1080mse dia720 dia720mse tss720 tdl720 gme720 gme720dev gme1080 gme1080exh seq1080 tss_bs4sw2 gme_pan240_bs12fd5; do
