@@ -78,6 +78,7 @@ _SIGNATURES = {
     "gme_solve_fit_sums": (_i, [_vp, _c_f64p, _i, _i, _i, _i, _c_f64p, _c_i32p]),
     "gme_seq_gme_device_solve": (_i, [_vp, _i, _i, _i, _i, ctypes.c_double, _c_f64p, _c_i64p, _c_i32p]),
     "gme_seq_read_compensated": (_i, [_vp, _i, _c_u8p]),
+    "gme_seq_read_compensated_range": (_i, [_vp, _i, _i, _c_u8p]),
     "gme_seq_set_split_phase": (_i, [_vp, _i]),
     "gme_seq_wait": (_i, [_vp]),
     "gme_seq_poll": (_i, [_vp]),
@@ -546,6 +547,15 @@ class Sequence:
     def read_compensated(self, pair):
         out = np.empty((self.H, self.W), dtype=np.uint8)
         _check(self.lib.gme_seq_read_compensated(self.handle, pair, _p(out, _c_u8p)), self.lib)
+        return out
+
+    def read_compensated_range(self, first, count, out=None):
+        """Compensated frames of pairs first .. first+count-1 -> uint8[count, H, W] with one wait (into `out` if given)."""
+        if out is None:
+            out = np.empty((count, self.H, self.W), dtype=np.uint8)
+        if out.shape != (count, self.H, self.W) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous uint8[%d, %d, %d]" % (count, self.H, self.W))
+        _check(self.lib.gme_seq_read_compensated_range(self.handle, int(first), int(count), _p(out, _c_u8p)), self.lib)
         return out
 
 

@@ -106,7 +106,8 @@ __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, in
     l.anchor = (win_rows * pitch_dw + 3) & ~3;         // 16-byte aligned: anchor rows are read as b128
     l.best = (l.anchor + nb * ANCHOR_STRIDE + 1) & ~1; // 8-byte aligned
     l.count = l.best + 2 * nb;                         // [0] list length, [1] next tile, [3] streak of hostile tiles (persistent_tiles),
-                                                       // [4] patches phase C2 took off the list (scored or pruned), [5] patches C2 scored
+                                                       // [4] patches phase C2 took off the list (scored or pruned), [5] patches C2 scored,
+                                                       // [7] MSE: length of the second list (level 2 of the bound)
     l.a2 = l.count + 8;
     l.prev = l.a2 + nb;                                // [nb] scan index each wave's block of the previous tile ended with (third probe)
     l.own = l.prev + nb;                               // [nb][16] phase C2: the patches a crowded block's wave scores itself
@@ -497,7 +498,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
     uint32_t* ctr = d.dynamic ? d.status + GME_STATUS_TILECTR + 16 * xcd : nullptr;
     uint32_t drawn = 0;
     if (ctr && threadIdx.x == 0) drawn = atomicInc(ctr, 0xFFFFFFFFu);
-    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 3] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; }
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 3] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; lds[L.count + 7] = 0; }
     uint32_t stat_scored = 0, stat_listed = 0;             // thread 0's: patches scored exactly / left by the first upper bounds
     for (;;) {
         int tid = (int)threadIdx.x;
@@ -523,7 +524,7 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
             stat_scored += listed + c2_scored;
             stat_listed += listed + c2_off;
 #endif
-            lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0;
+            lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; lds[L.count + 7] = 0;
             if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
         }
         __syncthreads();

@@ -75,11 +75,77 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
     }
 }
 
+#ifndef SEA_MSE_TWO_LEVEL_FROM
+#define SEA_MSE_TWO_LEVEL_FROM 4      // window classes R >= this use the two-level bound (R = 5, sw 32: +6 %; R = 3, sw 16: +-0, real frames -3 %)
+#endif
+// Level 1 of the two-level bound (R >= SEA_MSE_TWO_LEVEL_FROM): the MAE kernel's quadrant bound L1 = sum_q |dS_q| (5.7 instructions per
+// candidate against 8 for the squared form).  SSD >= SAD^2 / 256 >= L1^2 / 256 (Cauchy-Schwarz over the 256 pixels, then the
+// triangle inequality per quadrant), so a patch whose smallest L1 has L1^2 > 256 UB holds no winner; the squared form --
+// never weaker -- is applied as level 2 to the patches that pass, one lane per patch (bounds2_patch).
+template <int R, bool GUARD>
+__device__ __forceinline__ void lower_bounds_l1(const uint64_t* sp0, int XQ, int prow, int q, uint32_t a01, uint32_t a23,
+                                                int lo_r, int hi_r, int lo_c, int hi_c, uint32_t (&pkey)[R])
+{
+#pragma unroll
+    for (int k = 0; k < R; ++k) pkey[k] = 0xFFFFFFFFu;
+    const uint64_t* top = sp0;
+    const uint64_t* bot = sp0 + 8 * XQ;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int ri = prow * R + i;
+        if (!GUARD || (ri >= lo_r && ri <= hi_r)) {
+            uint64_t t[R + 2], b[R + 2];
+#pragma unroll
+            for (int k = 0; k < R + 2; ++k) { t[k] = top[k]; b[k] = bot[k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int ci0 = q * 4 * R + 4 * k;
+                if (GUARD && (ci0 > hi_c || ci0 + 3 < lo_c)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (GUARD && (ci0 + e < lo_c || ci0 + e > hi_c)) continue;
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t tp = __builtin_amdgcn_perm((uint32_t)(t[k + 2] >> (32 * (e >> 1))), (uint32_t)(t[k] >> (32 * (e >> 1))), sel);
+                    const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b[k + 2] >> (32 * (e >> 1))), (uint32_t)(b[k] >> (32 * (e >> 1))), sel);
+                    const uint32_t lb = __builtin_amdgcn_sad_u16(tp, a01, __builtin_amdgcn_sad_u16(bt, a23, 0u));
+                    pkey[k] = min(pkey[k], (lb << 13) + (uint32_t)((4 * k + e) * R + i));
+                }
+            }
+        }
+        top += XQ;
+        bot += XQ;
+    }
+}
+
+// Level 2: floor(LBx / 32) of the best of a patch's 4 x R candidates (the squared quadrant bound of lower_bounds_mse), by ONE
+// lane for a patch of any block of the tile.  No validity guards: a candidate outside the frame can only make the patch's
+// bound smaller (the patch is then scored for nothing, never dropped wrongly); phase E builds keys from valid candidates only.
+template <int R>
+__device__ __forceinline__ uint32_t bounds2_patch(const uint64_t* sp, int XQ, int k, uint32_t a01m, uint32_t a23m)
+{
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint64_t t0 = sp[i * XQ + k], t2 = sp[i * XQ + k + 2], b0 = sp[(i + 8) * XQ + k], b2 = sp[(i + 8) * XQ + k + 2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+            const uint32_t tp = __builtin_amdgcn_perm((uint32_t)(t2 >> (32 * (e >> 1))), (uint32_t)(t0 >> (32 * (e >> 1))), sel);
+            const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b2 >> (32 * (e >> 1))), (uint32_t)(b0 >> (32 * (e >> 1))), sel);
+            const s16x2 dt = __builtin_bit_cast(s16x2, pk_mad_i16(tp, 0x00020002u, a01m));
+            const s16x2 db = __builtin_bit_cast(s16x2, pk_mad_i16(bt, 0x00020002u, a23m));
+            best = min(best, (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false));
+        }
+    }
+    return best >> 7;                                      // 4 LBx >> 7 = floor(LBx / 32)
+}
+
 // Phases A' .. F of one tile (entry conditions as tile_phases() of bbme_sea.hip, plus a2s[] filled).
 template <int R, int LPPT>
 __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, const Layout& L, int pair, int trow, int bcol0,
                                                 uint32_t mine, uint32_t a01, uint32_t a23, uint32_t mine2, int tid, int tile_id)
 {
+    constexpr bool TWO = R >= SEA_MSE_TWO_LEVEL_FROM;     // two-level bound: L1 form for every candidate, squared form for the listed patches
     const int T = blockDim.x;
     const int NC = 2 * d.sw + 16, XQ = d.xq;
     uint32_t* win = lds + L.win;
@@ -108,15 +174,31 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         const int lo_c = max(0, d.sw - c0), hi_c = min(NC - 1, d.W - 16 - c0 + d.sw);
         uint32_t pkey[R];
         const uint64_t* sp0 = s8 + (16 * wb.wr + prow * R) * XQ + wb.wc * 4 + q * R;
-        if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
-            lower_bounds_mse<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
-        else
-            lower_bounds_mse<R, true>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
-        uint32_t patch_lb[R], lb_key = 0xFFFFFFFFu;
+        uint32_t patch_lb[R], lb_key = 0xFFFFFFFFu;        // patch_lb: the patch's smallest bound (TWO: L1; else floor(LBx / 32), 25 bits)
+        if constexpr (TWO) {
+            // plain quadrant sums back from their "minus twice" form (prep): halves are multiples of 2 <= 32640 in magnitude
+            const uint32_t p01 = __builtin_bit_cast(uint32_t, (s16x2)(-__builtin_bit_cast(s16x2, a01))) >> 1 & 0x7FFF7FFFu;
+            const uint32_t p23 = __builtin_bit_cast(uint32_t, (s16x2)(-__builtin_bit_cast(s16x2, a23))) >> 1 & 0x7FFF7FFFu;
+            if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
+                lower_bounds_l1<R, false>(sp0, XQ, prow, q, p01, p23, lo_r, hi_r, lo_c, hi_c, pkey);
+            else
+                lower_bounds_l1<R, true>(sp0, XQ, prow, q, p01, p23, lo_r, hi_r, lo_c, hi_c, pkey);
+            if (lane == 0) { lds[L.own + 2 * wave] = a01; lds[L.own + 2 * wave + 1] = a23; }      // level 2 serves any block of the tile
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 7;      // floor(LBx / 32), 25 bits
-            lb_key = min(lb_key, pkey[k]);
+            for (int k = 0; k < R; ++k) {
+                patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 13;
+                lb_key = min(lb_key, pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((pkey[k] >> 13) << 7) | (pkey[k] & 127u));   // bound << 7 | local, as below
+            }
+        } else {
+            if (rows_inside && lo_c == 0 && hi_c == NC - 1)                                // wave-uniform
+                lower_bounds_mse<R, false>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
+            else
+                lower_bounds_mse<R, true>(sp0, XQ, prow, q, a01, a23, lo_r, hi_r, lo_c, hi_c, pkey);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                patch_lb[k] = pkey[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : pkey[k] >> 7;      // floor(LBx / 32), 25 bits
+                lb_key = min(lb_key, pkey[k]);
+            }
         }
         // ---- C
         const uint32_t lb_min = wave_min_u32(lb_key);      // the zero vector is always valid: never the sentinel
@@ -158,24 +240,61 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         // of the best one.  Flat or static content then leaves (almost) nothing instead of everything.
         const bool exact = (ub_key >> 13) == 0;
         const uint32_t ub_idx = (uint32_t)ub_key & 0x1FFFu, first_idx = (uint32_t)((q * 4 * R) * NC + prow * R);
+        if constexpr (TWO) {
+            const uint32_t ub256 = (uint32_t)(ub_key >> 13) << 8;          // 256 ssd < 2^32
 #pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (patch_lb[k] <= ub25 && (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
-                const uint32_t slot = atomicAdd(count, 1u);
-                work[slot] = ((uint32_t)wave << 28) | ((uint32_t)lane << 22) | ((uint32_t)k << 19) | (patch_lb[k] >> 6);   // NB <= 16 waves
-            }
+            for (int k = 0; k < R; ++k)
+                if (patch_lb[k] != 0xFFFFFFFFu && __umul24(patch_lb[k], patch_lb[k]) <= ub256 &&      // L1 <= 65280: the square fits 32 bits
+                    (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
+                    const uint32_t slot = atomicAdd(count, 1u);
+                    work[slot] = ((uint32_t)wave << 28) | ((uint32_t)lane << 22) | ((uint32_t)k << 19);
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (patch_lb[k] <= ub25 && (!exact || (patch_lb[k] == 0 && first_idx + (uint32_t)(4 * k * NC) < ub_idx))) {
+                    const uint32_t slot = atomicAdd(count, 1u);
+                    work[slot] = ((uint32_t)wave << 28) | ((uint32_t)lane << 22) | ((uint32_t)k << 19) | (patch_lb[k] >> 6);   // NB <= 16 waves
+                }
+        }
+        (void)ub25;
     }
     __syncthreads();
     if (d.redo_list && (int)*count > d.redo_threshold) {     // workgroup-uniform: hostile tile, brute force is cheaper
         if (tid == 0) push_redo(d, tile_id, (int)(blockIdx.x & 7));
         return true;
     }
+    // ---- D2 (TWO): level 2 -- the squared bound of the listed patches, one lane per patch; survivors go to a second list at the far
+    // end of `work` (the lists cannot meet while the first holds at most half of the tile's patches; a longer one is scored as it is)
+    const uint32_t* list = work;
+    int n = (int)*count;
+    if constexpr (TWO) {
+        if (2 * n <= d.nb * 64 * R) {
+            for (int base = 0; base < n; base += T) {
+                const int e = base + tid;
+                if (e < n) {
+                    const uint32_t ent = work[e];
+                    const int w2 = ent >> 28, l2 = (ent >> 22) & 63, k2 = (ent >> 19) & 7;
+                    const int wr2 = div_small(w2, d.magic_tc), wc2 = w2 - wr2 * d.tc;
+                    const uint64_t* sp = s8 + (16 * wr2 + (l2 >> 2) * R) * XQ + wc2 * 4 + (l2 & 3) * R;
+                    const uint32_t lb25 = bounds2_patch<R>(sp, XQ, k2, lds[L.own + 2 * w2], lds[L.own + 2 * w2 + 1]);
+                    const unsigned long long ub2 = best[w2];
+                    const uint32_t fidx = (uint32_t)(((l2 & 3) * 4 * R + 4 * k2) * NC + (l2 >> 2) * R);
+                    if (lb25 <= (uint32_t)(ub2 >> 12) && ((ub2 >> 13) != 0 || (lb25 == 0 && fidx < ((uint32_t)ub2 & 0x1FFFu))))
+                        work[d.nb * 64 * R - 1 - (int)atomicAdd(count + 7, 1u)] = (ent & 0xFFF80000u) | (lb25 >> 6);
+                }
+            }
+            __syncthreads();
+            n = (int)count[7];
+            list = work + d.nb * 64 * R - n;                       // entries were stored downwards: any order will do
+            if (tid == 0) count[0] = (uint32_t)n;                  // statistics: patches scored (count[7] is cleared with the other counters at the next tile's start)
+        }
+    }
 
     // ---- E: LPP lanes per listed patch; lane `sub` takes anchor rows AR*sub .. AR*sub+AR-1 (R+AR-1 window
     // rows), the partial dot products are added inside the quad with DPP moves.  Four lanes per patch
     // repeat some v_alignbyte work but put four times as many waves on the (long) evaluation.
     constexpr int LPP = LPPT, AR = 16 / LPP;
-    const int n = (int)*count;
     const SqTable tab = sq_table(d.sqbox + (long long)pair * d.sqbox_stride, d.H, d.pitch);
     for (int base = 0; base < n; base += T / LPP) {
         const int e = base + tid / LPP;
@@ -183,7 +302,7 @@ __device__ __forceinline__ bool tile_phases_mse(const SeaDev& d, uint32_t* lds, 
         bool active = e < n;
         uint32_t ent = 0;
         if (active) {
-            ent = work[e];
+            ent = list[e];
             active = (ent & 0x7FFFFu) <= (uint32_t)(best[ent >> 28] >> 18);          // floor(LBx / 2^11) vs ssd >> 5
         }
         const int w2 = ent >> 28, l2 = (ent >> 22) & 63, k2 = (ent >> 19) & 7;
@@ -344,7 +463,7 @@ __global__ void __launch_bounds__(1024) k_exh_sea16_mse(SeaDev d)
     }
     const typename MseTile<R, LPPT>::Pre pre = MseTile<R, LPPT>::prep(d, lds, L, wave, lane, wb.ok, mine);
     if (lane == 0) lds[L.prev + wave] = (uint32_t)(d.sw * (2 * d.sw + 16) + d.sw);       // no previous tile: the zero vector
-    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; }
+    if (threadIdx.x == 0) { lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; lds[L.count + 7] = 0; }
     __syncthreads();
     MseTile<R, LPPT>::phases(d, lds, L, pair, trow, bcol0, mine, pre, (int)threadIdx.x, tile_number(d, pair, trow, bcol0));
     if (threadIdx.x == 0) {                                // list length is final behind phase D

@@ -1296,6 +1296,22 @@ extern "C" int gme_seq_compensate(gme_seq* s, int fd, int bs, const double* para
     return GME_OK;
 }
 
+// `count` compensated frames starting at pair `first` into out[count][H][W] (tight) with ONE wait: what results.py's
+// per-pair imwrite loop (results.py:59-76) needs of a finished chunk (a blocking read per pair stalled the one host
+// thread that drives all lanes of sequence.StreamEstimator).
+extern "C" int gme_seq_read_compensated_range(gme_seq* s, int first, int count, uint8_t* out)
+{
+    GME_REQUIRE(s != nullptr && out != nullptr, GME_ERR_ARG, "gme_seq_read_compensated_range: null pointer");
+    GME_ENTER(s->ctx);
+    GME_REQUIRE(s->comp.ptr && first >= 0 && count >= 0 && first + count <= s->comp.count, GME_ERR_STATE,
+                "gme_seq_read_compensated_range: pairs %d .. %d of %d", first, first + count, s->comp.ptr ? s->comp.count : 0);
+    for (int k = 0; k < count; ++k)
+        GME_HIP_TRY(hipMemcpy2DAsync(out + (size_t)k * s->H * s->W, s->W, s->comp.at(first + k), s->comp.pitch, s->W, s->H,
+                                     hipMemcpyDeviceToHost, s->ctx->stream));
+    GME_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    return GME_OK;
+}
+
 // The device solve on its own (what gme_seq_gme_device_solve runs between its stages), for callers and tests that hold
 // normal-equation sums: sums[P][15] = F | Sx | Sy -> params_out[P][6] (first components doubled if `project`,
 // motion.py:191-207) and flags_out[P]: bit 1 where a displacement of the h x w model field of those parameters lies within

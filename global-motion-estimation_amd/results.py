@@ -44,23 +44,22 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
     # the video stays in host memory and streams through a few lanes: one lane's upload runs beside the other lanes'
     # kernels, one host thread drives all of them (split-phase calls) and does their 3x3 solves in between; every device
     # object is released before this returns
-    n_pairs = len(frames) - fd
-    compensated_all = np.empty((n_pairs,) + tuple(shape), np.uint8) if save_path is not None else None
     solve = None
     if model != "affine":
         import roadmap
         solve = lambda sums: roadmap.solve_model(sums, model)       # noqa: E731
-    params, psnr = estimate_stream(frames, fd, chunk_pairs=CHUNK_PAIRS, streams=STREAMS, compensated=compensated_all, solve=solve)
     field_shape = (int(shape[0] / bs), int(shape[1] / bs), 2)
-    for idx in range(fd, len(frames)):
-        p = idx - fd
-        if progress:
-            j = (idx + 1) / len(frames)
-            print("[%-20s] %d/%d frames" % ("=" * int(20 * j), idx, len(frames)))
-        if save_path is not None:
-            previous, current = frames[p], frames[idx]
-            compensated = compensated_all[p]
-            model_motion_field = motion.get_motion_field_affine(field_shape, parameters=params[p])
+    written = {}
+
+    def write_chunk(p0, p1, comp, params, psnr):
+        """The image sets of one finished chunk (results.py:62-106) and the records so far (results.py:109-112).  The chunk's
+        compensated frames come in one read and memory stays bounded by the chunk (a whole-video host array of
+        compensated frames -- 4 GB for 2000 frames of 1080p -- and one blocking read per pair used to stall the host thread
+        that drives all lanes)."""
+        for k in range(p1 - p0):
+            p, idx = p0 + k, p0 + k + fd
+            previous, current, compensated = frames[p], frames[idx], comp[k]
+            model_motion_field = motion.get_motion_field_affine(field_shape, parameters=params[k])
             write_image(os.path.join(save_path, "frames", "") + str(idx - 5) + ".png", previous)
             write_image(os.path.join(save_path, "compensated", "") + str(idx - 5) + ".png", compensated)
             diff_curr_prev = np.absolute(current.astype("int") - previous.astype("int")).astype("uint8")
@@ -69,11 +68,25 @@ def process_frames(frames, frame_distance=FRAME_DISTANCE, save_path=None, progre
             write_image(os.path.join(save_path, "curr_comp_diff", "") + str(idx) + ".png", diff_curr_comp)
             write_image(os.path.join(save_path, "model_motion_field", "") + str(idx) + ".png",
                         draw_motion_field(previous, model_motion_field))
+            written[idx] = str(-1 if psnr[k] == -1 else complex(psnr[k], 0.0))
+        with open(save_path + "psnr_records.json", "w") as outfile:        # chunks of different lanes may finish out of order
+            dump({str(i): written[i] for i in sorted(written)}, outfile)
+
+    # the video stays in host memory and streams through a few lanes: one lane's upload runs beside the other lanes'
+    # kernels, one host thread drives all of them (split-phase calls) and does their 3x3 solves in between; every device
+    # object is released before this returns
+    params, psnr = estimate_stream(frames, fd, chunk_pairs=CHUNK_PAIRS, streams=STREAMS, solve=solve,
+                                   on_chunk=write_chunk if save_path is not None else None)
+    for idx in range(fd, len(frames)):
+        p = idx - fd
+        if progress:
+            j = (idx + 1) / len(frames)
+            print("[%-20s] %d/%d frames" % ("=" * int(20 * j), idx, len(frames)))
         value = psnr[p]
         psnr_dict[str(idx)] = str(-1 if value == -1 else complex(value, 0.0))       # utils.PSNR returns cmath complex
-        if save_path is not None:
-            with open(save_path + "psnr_records.json", "w") as outfile:
-                dump(psnr_dict, outfile)
+    if save_path is not None:
+        with open(save_path + "psnr_records.json", "w") as outfile:
+            dump(psnr_dict, outfile)
     return psnr_dict
 
 

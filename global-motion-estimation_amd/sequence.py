@@ -646,7 +646,10 @@ class StreamEstimator:
             p0 += c
         return out
 
-    def run(self, frames, compensated=None, exact_psnr=True, solve=None):
+    def run(self, frames, compensated=None, exact_psnr=True, solve=None, on_chunk=None):
+        """``on_chunk(p0, p1, comp, params, psnr)`` is called as each chunk finishes (chunks of different lanes may finish out
+        of order) with its compensated frames uint8[p1 - p0, H, W] (one read for the chunk; the array is reused by the next
+        chunk of the same lane), parameters and PSNR: what results.py writes per pair, without a whole-video array on the host."""
         fd, H, W, cap = self.fd, self.H, self.W, self.cap
         P = max(0, len(frames) - fd)
         params_out, sse_out = np.zeros((P, 6)), np.zeros(P, dtype=np.int64)
@@ -702,8 +705,15 @@ class StreamEstimator:
             params_out[p0:p1] = lane.params
             sse_out[p0:p1] = lane.pending[:n]
             if compensated is not None:
-                for k in range(n):
-                    compensated[p0 + k] = seq.read_compensated(k)
+                seq.read_compensated_range(0, n, compensated[p0:p1])      # one wait for the chunk, not one per pair
+            if on_chunk is not None:
+                if compensated is not None:
+                    comp = compensated[p0:p1]
+                else:
+                    if getattr(lane, "comp_host", None) is None:
+                        lane.comp_host = np.empty((cap, H, W), np.uint8)
+                    comp = seq.read_compensated_range(0, n, lane.comp_host[:n])
+                on_chunk(p0, p1, comp, lane.params[:n], psnr_from_sse(lane.pending[:n], H, W, exact_psnr))
             lane.stage = 0
             return True
 
@@ -733,7 +743,7 @@ class StreamEstimator:
         return params_out, psnr_from_sse(sse_out, H, W, exact_psnr)
 
 
-def estimate_stream(frames, frame_distance=1, chunk_pairs=512, streams=2, ctx=None, compensated=None, procedure=3,
+def estimate_stream(frames, frame_distance=1, chunk_pairs=512, streams=2, ctx=None, compensated=None, procedure=3, on_chunk=None,
                     search_window=2, exact_psnr=True, solve=None, min_chunk=64):
     """One-shot StreamEstimator: allocate the lanes, run `frames` through them, release them
     -> (params float64[P, 6], psnr float64[P]).  Setting the lanes up costs a few milliseconds each; callers with
@@ -747,4 +757,4 @@ def estimate_stream(frames, frame_distance=1, chunk_pairs=512, streams=2, ctx=No
     n_chunks = (P + chunk_pairs - 1) // chunk_pairs
     with StreamEstimator(H, W, frame_distance, chunk_pairs, max(1, min(int(streams), n_chunks)), ctx, procedure, search_window,
                          min_chunk=min_chunk) as est:
-        return est.run(frames, compensated=compensated, exact_psnr=exact_psnr, solve=solve)
+        return est.run(frames, compensated=compensated, exact_psnr=exact_psnr, solve=solve, on_chunk=on_chunk)

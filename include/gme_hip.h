@@ -189,6 +189,9 @@ GME_API int gme_seq_gme_read_stage(gme_seq *seq, int level, int pair, int32_t *g
 GME_API int gme_seq_compensate(gme_seq *seq, int frame_distance, int block_size, const double *params,
                        int64_t *sse_out);
 GME_API int gme_seq_read_compensated(gme_seq *seq, int pair, uint8_t *out);
+/* the compensated frames of pairs first .. first+count-1 into out[count][H][W] (tight), one wait for all of them: a finished
+ * chunk of a streamed video for results.py's writers (results.py:59-76) */
+GME_API int gme_seq_read_compensated_range(gme_seq *seq, int first, int count, uint8_t *out);
 /* Opt-in one-call form of begin_fit -> solve -> fit(2) -> solve -> compensate with the two 3x3 solves of
  * motion.py:262-264,280-282 on the device: one host round trip per estimate instead of three.  LAPACK's last bits are not
  * reproduced: params_out[P][6] is within rtol 1e-10 of the staged path's (motion.py:109-136); model fields, masks,
