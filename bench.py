@@ -771,7 +771,7 @@ def measure(opt, ctx, comm, rank, world):
     # this same command (profiles/): valid only for the kernels they were taken from (kernel_source_sha)
     plan_kernel = info["plan"].split(" ")[0] if info.get("plan") else None
     vals, psha, pname = committed_profile(opt.config, plan_kernel)
-    switches = sorted(k for k in os.environ if k.startswith("GME_") and k not in ("GME_DEVICE",))
+    switches = sorted(k for k in os.environ if k.startswith("GME_") and k not in ("GME_DEVICE",) and k not in extra.get("env", {}))
     if proc == 0:
         ops = byte_ops_per_pair(H, W, bs, sw) * B / (kernel_ms * 1e-3)
         out["brute_force_equivalent"] = {

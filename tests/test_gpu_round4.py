@@ -270,3 +270,40 @@ def test_device_solve_flags_ties_and_singular_systems(golden, native):
     s = np.concatenate([Fs.reshape(-1), Fs @ p[:3], Fs @ p[3:]])
     _, flags = ctx.solve_fit_sums(s[None], 30, 45)
     assert flags[0] & 4
+
+
+def test_stream_on_chunk_delivers_every_pair_once(golden, native):
+    """results.py takes a finished chunk's compensated frames in ONE read (gme_seq_read_compensated_range) through
+    StreamEstimator.run(on_chunk=...) instead of a whole-video host array and a blocking read per pair.  Every pair of the
+    reference's 51 real frames must arrive exactly once (chunks of different lanes may finish out of order), with the
+    parameters / PSNR the call returns and the compensated frame the reference wrote (g9)."""
+    import sequence
+    g = golden("g9_pan240seq")
+    frames = g["frames"]
+    got = {}
+
+    def on_chunk(p0, p1, comp, params, psnr):
+        assert comp.shape == (p1 - p0, 240, 320) and comp.dtype == np.uint8
+        for k in range(p1 - p0):
+            assert p0 + k not in got
+            got[p0 + k] = (sha(comp[k]), np.array(params[k]), float(psnr[k]))
+
+    params, psnr = sequence.estimate_stream(frames, 1, chunk_pairs=7, streams=3, on_chunk=on_chunk, min_chunk=1)
+    assert sorted(got) == list(range(50))
+    for p in range(50):
+        assert got[p][0] == str(g["bs16_fd1_i%d_comp_sha" % (p + 1)]), p
+        assert np.array_equal(got[p][1], params[p]) and got[p][2] == psnr[p]
+    # the ranged read equals the per-pair one
+    ctx = native.default_context()
+    seq = native.Sequence.from_frames(ctx, frames[:9])
+    try:
+        import motion
+        p = motion.estimate_sequence(seq, 1)
+        seq.compensate(1, 16, p)
+        block = seq.read_compensated_range(2, 5)
+        for k in range(5):
+            assert np.array_equal(block[k], seq.read_compensated(2 + k))
+        with pytest.raises(Exception):
+            seq.read_compensated_range(6, 5)                    # beyond the 8 pairs
+    finally:
+        seq.close()
