@@ -111,11 +111,7 @@ __host__ __device__ constexpr Layout make_layout(int R, int nb, int win_rows, in
     l.a2 = l.count + 8;
     l.prev = l.a2 + nb;                                // [nb] scan index each wave's block of the previous tile ended with (third probe)
     l.own = l.prev + nb;                               // [nb][16] phase C2: the patches a crowded block's wave scores itself
-#ifdef SEA_NO_OWN
-    l.s8 = (l.own + 1) & ~1;
-#else
     l.s8 = (l.own + 16 * nb + 1) & ~1;                 // 8-byte aligned, [s8_rows][xq] u16x4
-#endif
     l.work = l.s8 + 2 * s8_rows * xq;                  // [nb*64*R] entries
     l.total = l.work + nb * 64 * R;
     return l;
@@ -519,11 +515,9 @@ __device__ __forceinline__ void persistent_tiles(const SeaDev& d, uint32_t* lds,
         const typename Kern::Pre pre = Kern::prep(d, lds, L, wave, lane, wave_block(d, trow_c, bcol0_c, wave).ok, mine);
         if (tid == 0) {
             // the finished tile's counts (final behind its phase D barrier) -> statistics, then cleared for this tile
-#ifndef SEA_NO_STATS
             const uint32_t listed = lds[L.count], c2_off = lds[L.count + 4], c2_scored = lds[L.count + 5];
             stat_scored += listed + c2_scored;
             stat_listed += listed + c2_off;
-#endif
             lds[L.count] = 0; lds[L.count + 4] = 0; lds[L.count + 5] = 0; lds[L.count + 7] = 0;
             if (ctr) lds[L.count + 1] = (uint32_t)gx + drawn;
         }

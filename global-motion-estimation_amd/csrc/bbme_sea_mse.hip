@@ -65,7 +65,10 @@ __device__ __forceinline__ void lower_bounds_mse(const uint64_t* sp0, int XQ, in
                     // (lbx >> 5) << 7 needed a shift and a shift-add (round 4: 9 -> 8 instructions per candidate)
                     const s16x2 dt = __builtin_bit_cast(s16x2, pk_mad_i16(tp, 0x00020002u, a01));    // a01, a23: MINUS twice the anchor's sums; |d| <= 32640
                     const s16x2 db = __builtin_bit_cast(s16x2, pk_mad_i16(bt, 0x00020002u, a23));
-                    const uint32_t lbx4 = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false);
+                    // clamp = true only to get the VOP3P form (the VOP2 form v_dot2c needs its accumulator moved into place: a
+                    // v_mov per candidate); saturation at 2^31 - 1 -- reachable only where 4 LBx >= 2^31, far above any upper
+                    // bound -- makes a bound smaller, never larger, so it stays a lower bound
+                    const uint32_t lbx4 = (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, true), true);
                     pkey[k] = min(pkey[k], (lbx4 & ~127u) | (uint32_t)((4 * k + e) * R + i));          // local < 4R*R <= 100 < 128
                 }
             }
@@ -134,7 +137,7 @@ __device__ __forceinline__ uint32_t bounds2_patch(const uint64_t* sp, int XQ, in
             const uint32_t bt = __builtin_amdgcn_perm((uint32_t)(b2 >> (32 * (e >> 1))), (uint32_t)(b0 >> (32 * (e >> 1))), sel);
             const s16x2 dt = __builtin_bit_cast(s16x2, pk_mad_i16(tp, 0x00020002u, a01m));
             const s16x2 db = __builtin_bit_cast(s16x2, pk_mad_i16(bt, 0x00020002u, a23m));
-            best = min(best, (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, false), false));
+            best = min(best, (uint32_t)__builtin_amdgcn_sdot2(dt, dt, __builtin_amdgcn_sdot2(db, db, 0, true), true));       // clamp: see lower_bounds_mse
         }
     }
     return best >> 7;                                      // 4 LBx >> 7 = floor(LBx / 32)
