@@ -1,24 +1,27 @@
 // Walk searches (diamond, three-step, 2-D log) specialised for the two geometries the
 // global-motion pipeline runs all the time (motion.py:27-29,224-229):
 //
-//   k_walk16<PNORM> (diamond), k_walk16s<PNORM, PROC> (three-step, 2-D log)  bs = 16: one wavefront per macroblock, 8 blocks per wave one after the other (the
-//                     next block's anchors and first window are fetched while the current one is walked, two
-//                     register sets used in turn).  The wave is cut into 8 groups
-//                     of 8 lanes; a group evaluates one candidate per round, each lane owning
+//   k_walk16<PNORM> (diamond), k_walk16s<PNORM, PROC, FITS> (three-step, 2-D log)  bs = 16: one wavefront per macroblock,
+//                     8 blocks per wave one after the other (the next block's anchors -- and, for the diamond and the
+//                     three-step search, its first window -- are fetched while the current one is walked, two register
+//                     sets used in turn; the wave steps its block's grid position instead of dividing).  The wave is cut
+//                     into 8 groups of 8 lanes; a group evaluates one candidate per round, each lane owning
 //                     two 16-byte rows of the block, s and s + 8 (ten dwords of the per-wave LDS window of
 //                     `cur`, 8 v_alignbyte_b32, 8 v_sad_u8 or 16 v_dot4_u32_u8 against its 8
 //                     anchor dwords kept in VGPRs), followed by a 3-step DPP reduction inside
 //                     the group.  Up to 8 candidates cost one round; the centre of a pattern is
-//                     the previous winner, whose cost is carried instead of recomputed.  The window is
-//                     staged branch-free through a buffer resource (out-of-plane reads return 0).
+//                     the previous winner, whose cost is carried instead of recomputed (diamond: every round; three-step:
+//                     second step, and third when the first did not move; 2-D log: the closing ring).  Under MSE a block's
+//                     own sum of a^2 is a constant of every comparison the walk makes and is replaced by one (MSE_BIAS).
+//                     The window is staged branch-free through a buffer resource (out-of-plane reads return 0).
 //                     k_walk16 is the diamond search on its own (the GME levels 1-2): rounds pick
 //                     the winner in the vector unit (PATTERN_MIN), 41 vector + ~35 scalar instructions
 //                     per round of 8 candidates under MSE.  Three-step and 2-D log are instances of their own
 //                     (PROC): every group derives its candidate from its index, validity is a per-lane test, the
 //                     round's box is the pattern's span clipped to the frame (EVALV) and the winner comes
 //                     from the same DPP minimum -- no wave-uniform candidate arrays, no scalar spills.  Their LDS
-//                     window is 48 rows x 64 bytes (Win<true>): the first step of both searches at sw = 16 (span 32)
-//                     fits, so a block is usually staged once and never reads global memory directly.
+//                     window is 48 rows x 64 bytes (Win<true>): the widest round of both searches at sw <= 16 (span 32)
+//                     fits (FITS: no code that reads global memory directly); wider searches take the FITS = false instance.
 //   k_dense2<PNORM>   bs = 2, diamond: one lane per 2x2 block (the dense first estimate on the
 //                     coarsest pyramid level, 5400 blocks per 720x480 pair).
 //
@@ -44,6 +47,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint16_t u16_u __attribute__((aligned(1)));
 
 constexpr unsigned INF32 = 0xFFFFFFFFu;
+constexpr unsigned MSE_BIAS = 1u << 24;        // stands in for a block's sum of a^2 in the walk kernels' MSE costs (see walk_block)
 
 __device__ __forceinline__ int clamp_ref(int v, int hi)   // min(max(v, 0), hi), bbme.py:503-504
 {
@@ -98,7 +102,7 @@ __device__ __forceinline__ unsigned group_eval(const uint32_t (&a)[8], unsigned 
                 bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
                 ab = __builtin_amdgcn_udot4(a[j], b[j], ab, false);
             }
-            part = aa + bb - 2u * ab;          // sum over this lane's 32 pixels of (a-b)^2
+            part = aa + bb - 2u * ab;          // this lane's 32 pixels of b^2 - 2ab plus its share of MSE_BIAS
         }
     }
     part = group8_sum(part);
@@ -116,6 +120,10 @@ constexpr int WIN_ALLOC = 43 * WIN_PITCH;      // staging moves 128 sixteen-byte
 // lane, pitch 17 dwords: odd, so the 8 lanes of a group still hit 8 banks) hold a pattern of span 32 -- the first step
 // of both searches at sw = 16 -- so that round is served from the LDS as well instead of reading global memory through
 // unaligned loads, and the later, narrower rounds usually fall inside the same window: one staging per block.
+// which FITS searches fetch their first window ahead (bit PROC): it costs 12 VGPRs per prefetch buffer
+#ifndef WALK_FITS_PREFETCH
+#define WALK_FITS_PREFETCH (1 << GME_SEARCH_THREESTEP)
+#endif
 #ifndef WALK_SMALLWIN
 constexpr bool WALK_BIG = true;
 #else
@@ -213,7 +221,7 @@ __device__ __forceinline__ unsigned group_eval_at(const uint32_t (&a)[8], unsign
 #pragma unroll
             for (int j = 0; j < 8; ++j) part = __builtin_amdgcn_sad_u8(a[j], b[j], part);
         } else {
-            unsigned bb = aa, ab = 0;                      // sum a^2 rides in the b^2 chain: no separate add
+            unsigned bb = aa, ab = 0;                      // the lane's share of MSE_BIAS rides in the b^2 chain: no separate add
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
@@ -253,7 +261,7 @@ __device__ __forceinline__ unsigned group_eval_lds(const uint32_t (&a)[8], unsig
 }
 
 // cost of ONE candidate by all 64 lanes together, wave-uniform result: lane l takes dword l % 4 of block row l / 4 (two
-// window dwords, one v_alignbyte, one v_sad_u8 or three v_dot4), 7 DPP adds leave the sum in lane 63.  `origin` = LDS
+// window dwords, one v_alignbyte, one v_sad_u8 or two v_dot4), 7 DPP adds leave the sum in lane 63.  `origin` = LDS
 // byte address of window cell (row 0, column 0) in frame coordinates (window base - wr0 * row bytes - wc0).  A third of
 // the instructions of a group round that would keep 7 of the 8 groups idle: the diamond's first centre, the ninth
 // candidate of a three-step step and of the 2-D log's last ring.
@@ -266,7 +274,7 @@ __device__ __forceinline__ unsigned wave_eval_lds(uint32_t mine, int origin, int
     if (PNORM == 0) {
         part = __builtin_amdgcn_sad_u8(mine, b, 0u);
     } else {
-        const unsigned bb = __builtin_amdgcn_udot4(b, b, __builtin_amdgcn_udot4(mine, mine, 0u, false), false);
+        const unsigned bb = __builtin_amdgcn_udot4(b, b, MSE_BIAS / 64, false);
         const unsigned ab = __builtin_amdgcn_udot4(mine, b, 0u, false);
         asm("s_nop 2\n\tv_mad_i32_i24 %0, %1, -2, %2" : "=v"(part) : "v"(ab), "v"(bb));
     }
@@ -280,7 +288,7 @@ __device__ __forceinline__ unsigned wave_eval_lds(uint32_t mine, int origin, int
 // Four candidates, one per 16-lane row, one block row per lane (the diamond's small pattern: a group round would leave
 // half of the wave idle).  A lane's two block rows are lrow and lrow + 8 (walk_block), so lane r of a 16-lane row already
 // holds block row r: in a[0..3] when r < 8, in a[4..7] otherwise -- `arow` is that choice, no data moves.  Five window
-// dwords, 4 v_alignbyte, 4 v_sad_u8 or 12 v_dot4, 4 DPP adds leave the candidate's cost in every lane of its row.
+// dwords, 4 v_alignbyte, 4 v_sad_u8 or 8 v_dot4, 4 DPP adds leave the candidate's cost in every lane of its row.
 template <int PNORM>
 __device__ __forceinline__ unsigned row16_eval_at(const uint32_t (&arow)[4], int addr, uint32_t sh)
 {
@@ -296,10 +304,9 @@ __device__ __forceinline__ unsigned row16_eval_at(const uint32_t (&arow)[4], int
 #pragma unroll
         for (int j = 0; j < 4; ++j) part = __builtin_amdgcn_sad_u8(arow[j], b[j], part);
     } else {
-        unsigned bb = 0, ab = 0;
+        unsigned bb = MSE_BIAS / 16, ab = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bb = __builtin_amdgcn_udot4(arow[j], arow[j], bb, false);
             bb = __builtin_amdgcn_udot4(b[j], b[j], bb, false);
             ab = __builtin_amdgcn_udot4(arow[j], b[j], ab, false);
         }
@@ -341,25 +348,43 @@ __device__ __forceinline__ void axis_box(int org, int st, int limit, int& lo, in
 
 // What a wave fetches ahead for a block: its 2 anchor rows per lane and, for the diamond search (whose first
 // window position depends on the block alone), the lane's share of that window.
-struct WalkPre {
+template <int W> struct WalkPre {
     uint4 a0, a1;
-    uint32_t w[2][4];
+    uint32_t w[W][4];       // the lane's share of the block's first window (W = segments per lane of the search's window)
+    int wr0, wc0;           // that window's origin (wave-uniform)
     uint32_t mine;          // anchor dword (row lane / 4, dword lane % 4) for the all-lanes cost of one candidate (wave_eval_lds)
 };
 
 // first window of a diamond walk: the one PATTERN_MIN would stage around the clamped block origin
-__device__ __forceinline__ void first_window(const WalkDev& d, int blk, int& wr0, int& wc0)
+__device__ __forceinline__ void first_window(const WalkDev& d, int r0, int c0, int& wr0, int& wc0)
 {
-    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
     wr0 = clamp_ref(r0, d.H - 17) - (WIN_ROWS - 16) / 2;
     wc0 = max(0, (clamp_ref(c0, d.W - 17) - (WIN_SPAN - 3) / 2) & ~3);          // never left of the frame, see window_load
 }
 
-template <bool DIA>
-__device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int pair, int blk)
+// first window of a three-step / 2-D log walk whose patterns fit a window (FITS, see walk_block): the one EVALF would
+// stage for the first round's box, the span `st` (first step / sw) around the block clipped to the frame
+__device__ __forceinline__ void first_window_span(const WalkDev& d, int r0, int c0, int st, int& wr0, int& wc0)
+{
+    typedef Win<true> WS;
+    int rmin, rmax, cmin, cmax;
+    axis_box(r0, st, d.H - 16, rmin, rmax);
+    axis_box(c0, st, d.W - 16, cmin, cmax);
+    wr0 = rmin - ((WS::ROWS - 16 - (rmax - rmin)) >> 1);
+    wc0 = max(0, (cmin - ((WS::SPAN - 3 - (cmax - cmin)) >> 1)) & ~3);
+}
+
+template <int PROC, bool FITS> constexpr int walk_pre()
+{
+    return PROC == GME_SEARCH_DIAMOND ? 1 : FITS && ((WALK_FITS_PREFETCH >> PROC) & 1) ? 2 : 0;
+}
+
+// PRE = 0: anchors only; 1: + the diamond's first window; 2: + the first window of a three-step / 2-D log walk (FITS)
+template <int PRE, int W>
+__device__ __forceinline__ void walk_prefetch(WalkPre<W>& f, const WalkDev& d, int pair, int brow, int bcol)
 {
     const int lane = threadIdx.x & 63;
-    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
+    const int r0 = brow * 16, c0 = bcol * 16;
     // anchors through a buffer resource as well: 32-bit offsets instead of 64-bit pointer arithmetic per lane
     const __amdgpu_buffer_rsrc_t ra = plane_rsrc(d.prev + (long long)pair * d.plane_stride, d.H * d.pitch);
     const int aoff = __mul24(r0 + (lane & 7), d.pitch) + c0;                    // block rows s and s + 8 (see walk_block)
@@ -367,23 +392,32 @@ __device__ __forceinline__ void walk_prefetch(WalkPre& f, const WalkDev& d, int 
     const u32x4_t t1 = __builtin_amdgcn_raw_buffer_load_b128(ra, aoff + 8 * d.pitch, 0, 0);
     f.a0 = make_uint4(t0.x, t0.y, t0.z, t0.w); f.a1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
     f.mine = __builtin_amdgcn_raw_buffer_load_b32(ra, __mul24(r0 + (lane >> 2), d.pitch) + c0 + 4 * (lane & 3), 0, 0);
-    if (DIA) {
-        int wr0, wc0;
-        first_window(d, blk, wr0, wc0);
-        window_load(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, wr0, wc0, lane);
+    if constexpr (PRE == 1) {
+        first_window(d, r0, c0, f.wr0, f.wc0);
+        window_load<false>(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, f.wr0, f.wc0, lane);
+    } else if constexpr (PRE == 2) {
+        first_window_span(d, r0, c0, d.procedure == GME_SEARCH_THREESTEP ? d.st1 : d.sw, f.wr0, f.wc0);
+        window_load<true>(f.w, d.cur + (long long)pair * d.plane_stride, d.pitch, d.H, f.wr0, f.wc0, lane);
     }
 }
 
-// one 16x16 block of one frame pair, walked by one wave; PROC = GME_SEARCH_THREESTEP / TWODLOG / DIAMOND
-template <int PNORM, int PROC>
-__device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, const int blk, const int nblk, uint32_t* win,
-                                           const WalkPre& pre)
+// one 16x16 block of one frame pair, walked by one wave; PROC = GME_SEARCH_THREESTEP / TWODLOG / DIAMOND.
+// FITS (three-step, 2-D log): every round's box fits the 48 x 64 window (first step / sw <= 16), so there is no path
+// that reads global memory directly, the first window is fetched ahead like the diamond's, and a round is "inside the
+// staged window, else move it" -- about a fifth fewer scalar instructions per round (these kernels are bound by the
+// scalar unit, profiles/r04_final_tdl720_pmc_summary.txt: 1.3 scalar instructions per vector instruction).
+// `nxt`: the prefetch buffer of the wave's next block (brow_n, bcol_n), filled here if `more` -- after this block's
+// fetched-ahead window has gone to the LDS, so that the two buffers' window registers are never live together.
+template <int PNORM, int PROC, bool FITS, int NW>
+__device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, const int blk, const int brow, const int bcol,
+                                           const int nblk, uint32_t* win, const WalkPre<NW>& pre,
+                                           WalkPre<NW>& nxt, const bool more, const int brow_n, const int bcol_n)
 {
     constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
     constexpr bool SBIG = !DIA && WALK_BIG;                      // window geometry of this search (Win<>)
     typedef Win<SBIG> WS;
     const long long gid = (long long)pair * nblk + blk;
-    const int r0 = (blk / d.nbc) * 16, c0 = (blk % d.nbc) * 16;
+    const int r0 = brow * 16, c0 = bcol * 16;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, lrow = lane & 7;                 // group = candidate slot, lane = block rows lrow and lrow + 8
     const int H = d.H, W = d.W, pitch = d.pitch;
@@ -392,18 +426,17 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     uint32_t a[8];
     a[0] = pre.a0.x; a[1] = pre.a0.y; a[2] = pre.a0.z; a[3] = pre.a0.w;
     a[4] = pre.a1.x; a[5] = pre.a1.y; a[6] = pre.a1.z; a[7] = pre.a1.w;
-    unsigned aa = 0;
-    if (PNORM == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) aa = __builtin_amdgcn_udot4(a[j], a[j], aa, false);
-    }
+    // MSE: a walk only compares costs of ONE block, so the block's own sum of a^2 -- the same in every candidate's
+    // sum of (a - b)^2 = sum a^2 + sum b^2 - 2 sum a b -- is replaced by the constant 2^24 > 256 * 255^2: the order of the
+    // costs, ties included, is unchanged, 8 v_dot4 per block (and one per all-lanes evaluation) are not issued.  Every
+    // evaluation spreads the constant over its lanes (MSE_BIAS / lanes each); per-lane parts may wrap below zero, the
+    // sum over the block cannot: 2^24 + sum b^2 - 2 sum a b >= 2^24 - sum a^2 > 0, and < 2^26, so keys still fit 32 bits.
+    const unsigned aa = PNORM == 1 ? MSE_BIAS / 8 : 0u;
 
-    // evaluate n <= 8 candidates (cr[k], cc[k], ok[k]) -> cost[k], all wave-uniform.
-    // Candidates are served from the LDS window; when some fall outside it the window is moved
-    // (centred on their bounding box) and, if the pattern is wider than the window (first steps
-    // of three-step / 2-D log), this round reads global memory directly.
-    int wr0 = -(1 << 20), wc0 = 0;                  // far away: nothing staged yet (the diamond walk sets its first window itself)
-    bool round_lds = false;                         // the last EVALV round was served from the LDS window
+    // Candidates are served from the LDS window; when some fall outside it the window is moved (centred on their
+    // bounding box) and, if the pattern is wider than the window (!FITS: sw > 16), the round reads global memory directly.
+    int wr0 = -(1 << 20), wc0 = 0;                  // far away: nothing staged yet (the diamond and FITS walks set their first window themselves)
+    bool round_lds = FITS;                          // the last EVALV round was served from the LDS window
 #if defined(WALK_ABLATE) && WALK_ABLATE == 1      // timing experiments only (tools/build_variant.sh): anchors loaded, nothing else
     if (lane == 0) { int32_t* o = d.mf + gid * 2; o[0] = (int)(a[0] + a[7] + aa) >> 30; o[1] = 0; }
     return;
@@ -411,13 +444,13 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
     // cost of this lane's group's candidate (RR, CC, OK: per-lane values, equal inside a group) -> COST in every lane of
     // the group (INF32 if !OK).  [RMIN, RMAX] x [CMIN, CMAX] is a wave-uniform box that holds the round's valid
     // candidates (RMIN > RMAX: none): when it fits, the round is served from the LDS window, which is moved (centred on
-    // the box) if it does not cover it; a pattern wider than the window (first steps of three-step / 2-D log) reads
-    // global memory directly.
-    // Round 3: these kernels were bound by the SCALAR unit (2-D log: 2.3 scalar instructions per vector instruction,
-    // scalar issue 0.96 busy; profiles/r03_final_tdl720_pmc_summary.txt) -- wave-uniform booleans cost the compiler an
+    // the box) if it does not cover it; a pattern wider than the window reads global memory directly (!FITS only).
+    // These kernels are bound by the SCALAR unit -- wave-uniform booleans cost the compiler an
     // s_cmp + s_cselect_b64 each and an s_and_b64 per conjunction.  The tests are therefore sign tests of ORed
     // differences: "inside the staged window" is dr, rs - dr, dc, cs - dc all >= 0 (rs, cs: the slack of the box in a
     // window), "fits a window" is rs, cs - 3 >= 0 for a non-empty box; one s_or chain and one compare each.
+    // FITS: a box always fits.  An empty box (a three-step origin that left the frame, bbme.py:332-336) may move the
+    // window to a meaningless place: no lane reads it (nothing is valid), and the next round moves it again.
 #define EVALV(RR, CC, OK, RMIN, RMAX, CMIN, CMAX, COST)                                               \
     do {                                                                                             \
         const int rh_ = (RMAX) - (RMIN), ch_ = (CMAX) - (CMIN);                                      \
@@ -425,16 +458,23 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         const int dr_ = (RMIN) - wr0, dc_ = (CMIN) - wc0;                                            \
         bool lds_ok_ = true;                                                                         \
         if ((dr_ | (rs_ - dr_) | dc_ | (cs_ - dc_)) < 0) {                                           \
-            if ((rh_ | ch_ | rs_ | (cs_ - 3)) >= 0) {                                                \
+            if (FITS || (rh_ | ch_ | rs_ | (cs_ - 3)) >= 0) {                                        \
                 wr0 = (RMIN) - (rs_ >> 1);                                                           \
                 wc0 = max(0, ((CMIN) - ((cs_ - 3) >> 1)) & ~3);                                      \
                 stage_walk_window<SBIG>(win, cur, pitch, H, wr0, wc0, lane);                         \
             } else lds_ok_ = false;                                                                  \
         }                                                                                            \
-        COST = lds_ok_ ? group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow)  \
-                       : group_eval<PNORM>(a, aa, cur, pitch, RR, CC, OK, lrow);                     \
-        round_lds = lds_ok_;                                                                         \
+        if (FITS) {                                                                                  \
+            COST = group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow);       \
+        } else {                                                                                     \
+            COST = lds_ok_ ? group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow)  \
+                           : group_eval<PNORM>(a, aa, cur, pitch, RR, CC, OK, lrow);                 \
+            round_lds = lds_ok_;                                                                     \
+        }                                                                                            \
     } while (0)
+    // the same for a round whose box the staged window is known to hold (FITS: the first round of a block)
+#define EVALW(RR, CC, OK, COST)                                                                       \
+    do { COST = group_eval_lds<PNORM, SBIG>(a, aa, win, -wr0 * (4 * WS::PITCH) - wc0, RR, CC, OK, lrow); } while (0)
     // the ninth candidate of a round (wave-uniform position inside the round's box): by all lanes from the window the
     // round's first EVALV has just made sure of, else by group 0 like the other eight
 #define EVAL9(RR, CC, RMIN, RMAX, CMIN, CMAX, KEY)                                                    \
@@ -443,19 +483,25 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         if (ok9_ && round_lds) {                                                                     \
             const unsigned c_ = wave_eval_lds<PNORM, WS::PITCH>(pre.mine, lds_address(win) - wr0 * (4 * WS::PITCH) - wc0, RR, CC, lane); \
             KEY = min(KEY, (c_ << 4) | 8u);                                                          \
-        } else {                                                                                     \
+        } else if (!FITS) {                                                                          \
             const bool ok_ = grp == 0 && ok9_;                                                       \
             unsigned c_;                                                                             \
             EVALV(RR, CC, ok_, RMIN, RMAX, CMIN, CMAX, c_);                                          \
             KEY = min(KEY, ok_ ? (c_ << 4) | 8u : INF32);                                            \
         }                                                                                            \
     } while (0)
+    constexpr int PRE = walk_pre<PROC, FITS>();
+    if constexpr (PRE != 0) {                         // fetched ahead by walk_prefetch
+        wr0 = pre.wr0; wc0 = pre.wc0;
+        window_store<SBIG>(win, pre.w, lane);
+    }
+    if (more) walk_prefetch<PRE>(nxt, d, pair, brow_n, bcol_n);     // in flight during this block's walk
 
     int out0 = 0, out1 = 0;
     bool overrun = false;
     const int cap = 2 * (H + W) + 64;
 
-    if (DIA) {
+    if constexpr (DIA) {
         const int maxr = H - 16 - 1, maxc = W - 16 - 1;
         // (pr, pc): origin the pattern offsets are added to; (qr, qc): its clamped position = candidate 0 of the
         // pattern.  They differ only before the first round, when the block sits in the last block row / column
@@ -484,9 +530,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             WINDOW_RANGES();                                                                         \
         }                                                                                            \
     } while (0)
-        first_window(d, blk, wr0, wc0);                 // fetched ahead by walk_prefetch
-        window_store(win, pre.w, lane);
-        WINDOW_RANGES();
+        WINDOW_RANGES();                                // of the window fetched ahead (walk_prefetch), stored above
         // per-lane offsets of the large (groups 0..7) and small (groups 0..3) patterns, from nibble tables:
         // LDSP minus its centre (2,0),(1,1),(0,2),(-1,1),(-2,0),(-1,-1),(0,-2),(1,-1) as (row, col); the small
         // pattern's offsets are applied swapped (bbme.py:518-521): (0,1),(1,0),(0,-1),(-1,0)
@@ -567,11 +611,16 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 #undef PATTERN_MIN
 #undef RESTAGE_IF_OUTSIDE
 #undef WINDOW_RANGES
-    } else if (PROC == GME_SEARCH_THREESTEP) {
+    } else if constexpr (PROC == GME_SEARCH_THREESTEP) {
         // bbme.py:182-341.  Candidate k = 0..8 of a step st around (org_r, org_c): column offset (k / 3 - 1) st in the outer
         // loop, row offset (k % 3 - 1) st in the inner one; out-of-frame candidates are skipped, the first strict
-        // minimum wins.  Group g evaluates candidate g, candidate 8 takes a second round in group 0.
+        // minimum wins.  Group g evaluates candidate g, candidate 8 is evaluated by all lanes together (EVAL9).
+        // The centre of the SECOND step is the first step's winner (org = block + d1, bbme.py:260-261), a valid position
+        // whose cost is known: its key (that cost, k = 4) joins the minimum as it is, group 4 evaluates candidate 8
+        // instead and the step needs no ninth evaluation.  The same holds for the THIRD step when the first step stayed
+        // where it was (the usual case on slow content).
         const int ur = grp % 3 - 1, uc = grp / 3 - 1;              // this group's offset in units of the step
+        unsigned known = INF32;                                    // key of the step's centre (k = 4) when its cost is known
         int drow = 0, dcol = 0, trow = 0, tcol = 0, org_r = r0, org_c = c0;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -579,32 +628,44 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             int rmin, rmax, cmin, cmax;
             axis_box(org_r, st, H - 16, rmin, rmax);
             axis_box(org_c, st, W - 16, cmin, cmax);
+            const bool have = s == 1 || (s == 2 && known != INF32);         // wave-uniform; s == 1: always
+            const bool g4 = have && grp == 4;                               // group 4 takes candidate 8 then
             unsigned key;
             {
-                const int rr = org_r + ur * st, cc = org_c + uc * st;
+                const int rr = org_r + (g4 ? 1 : ur) * st, cc = org_c + (g4 ? 1 : uc) * st;
                 const bool ok = (unsigned)rr <= (unsigned)(H - 16) && (unsigned)cc <= (unsigned)(W - 16);   // 0 <= v <= limit
                 unsigned c;
-                EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
-                key = ok ? (c << 4) | (unsigned)grp : INF32;
+                if (PRE != 0 && s == 0) EVALW(rr, cc, ok, c);          // the window fetched ahead is this round's
+                else EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
+                key = ok ? (c << 4) | (g4 ? 8u : (unsigned)grp) : INF32;
             }
-            EVAL9(org_r + st, org_c + st, rmin, rmax, cmin, cmax, key);        // candidate 8 (wave-uniform position)
-            const unsigned kmin = groups_min(key);
+            if (!have) EVAL9(org_r + st, org_c + st, rmin, rmax, cmin, cmax, key);        // candidate 8 (wave-uniform position)
+            const unsigned kmin = min(groups_min(key), known);
             int kr = s == 0 ? drow : trow, kc = s == 0 ? dcol : tcol;       // nothing valid: the stale offsets stay (bbme.py:332-336)
             if (kmin != INF32) {
                 const int k = (int)(kmin & 15u);
                 kr = (k % 3 - 1) * st; kc = (k / 3 - 1) * st;
             }
-            if (s == 0) { drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol; }
-            else { trow = kr; tcol = kc; drow += trow; dcol += tcol; org_r += drow; org_c += dcol; }
+            if (s == 0) {
+                drow = kr; dcol = kc; org_r = r0 + drow; org_c = c0 + dcol;
+                known = (kmin & ~15u) | 4u;                         // the block's own position is always valid: kmin != INF32
+            } else {
+                // the third step's origin is org + (d1 + d2), the accumulated offset (bbme.py:332-336): the second step's
+                // winner org + d2 -- the one position whose cost is at hand -- only when the first step did not move
+                if (s == 1) known = (drow | dcol) == 0 ? (kmin & ~15u) | 4u : INF32;
+                trow = kr; tcol = kc; drow += trow; dcol += tcol; org_r += drow; org_c += dcol;
+            }
         }
         out0 = dcol; out1 = drow;
     } else {   // 2-D log, bbme.py:344-433
         // step > 2: centre, (+s, 0), (-s, 0), (0, +s), (0, -s) as (row, col) offsets, groups 0..4; step == 2: the ring
-        // (k / 3 - 1, k % 3 - 1) * 2 for k = 0..8, candidate 8 in a second round of group 0
+        // (k / 3 - 1, k % 3 - 1) * 2 for k = 0..8.  The ring's centre (k = 4) is where the last cross round ended, its
+        // cost known from that round: group 4 takes candidate 8 and the centre's key joins the minimum as it is.  Only a
+        // search that starts at step 2 (sw = 2: no cross round) evaluates the ninth candidate by all lanes (EVAL9).
         const int xr = grp == 1 ? 1 : grp == 2 ? -1 : 0;
         const int xc = grp == 3 ? 1 : grp == 4 ? -1 : 0;
-        const int gr = grp / 3 - 1, gc = grp % 3 - 1;
         int br = 0, bc = 0, pr = r0, pc = c0, step = d.sw, it = 0;
+        unsigned known = INF32;
         const unsigned rlim = (unsigned)(H - 16), clim = (unsigned)(W - 16);      // 0 <= v <= limit as one unsigned compare
         // The cross rounds (step > 2) and the one ring round that ends the walk (step == 2: bbme.py halves the step after
         // it whatever it found) are two pieces of code: no per-round selects between the two patterns.
@@ -617,7 +678,8 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             unsigned c;
             EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
             const unsigned kmin = groups_min(ok ? (c << 4) | (unsigned)grp : INF32);
-            if (kmin != INF32) {                                    // the centre is always valid, so this always holds
+            known = kmin;                                           // the centre is always valid, so never INF32
+            {
                 const int k = (int)(kmin & 15u);
                 br = pr + (k == 1 ? step : k == 2 ? -step : 0); bc = pc + (k == 3 ? step : k == 4 ? -step : 0);
             }
@@ -626,6 +688,10 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
             if (++it > cap) { overrun = true; break; }
         }
         if (step == 2 && !overrun) {
+            const bool have = known != INF32;                       // wave-uniform
+            known = have ? (known & ~15u) | 4u : INF32;
+            const bool g4 = have && grp == 4;
+            const int gr = g4 ? 1 : grp / 3 - 1, gc = g4 ? 1 : grp % 3 - 1;
             int rmin, rmax, cmin, cmax;
             axis_box(pr, 2, H - 16, rmin, rmax);
             axis_box(pc, 2, W - 16, cmin, cmax);
@@ -635,10 +701,10 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
                 const bool ok = (unsigned)rr <= rlim && (unsigned)cc <= clim;
                 unsigned c;
                 EVALV(rr, cc, ok, rmin, rmax, cmin, cmax, c);
-                key = ok ? (c << 4) | (unsigned)grp : INF32;
+                key = ok ? (c << 4) | (g4 ? 8u : (unsigned)grp) : INF32;
             }
-            EVAL9(pr + 2, pc + 2, rmin, rmax, cmin, cmax, key);
-            const unsigned kmin = groups_min(key);
+            if (!have) EVAL9(pr + 2, pc + 2, rmin, rmax, cmin, cmax, key);
+            const unsigned kmin = min(groups_min(key), known);
             if (kmin != INF32) {
                 const int k = (int)(kmin & 15u);
                 br = pr + (k / 3 - 1) * 2; bc = pc + (k % 3 - 1) * 2;
@@ -648,6 +714,7 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
         out1 = br - r0; out0 = bc - c0;
     }
 #undef EVAL9
+#undef EVALW
 #undef EVALV
     if (lane == 0) {
         if (overrun) atomicExch(d.status, 1);
@@ -658,10 +725,20 @@ __device__ __forceinline__ void walk_block(const WalkDev& d, const int pair, con
 
 // Workgroup = 4 waves, each wave walks d.bpw blocks one after the other (blocks base, base + 4, ...): the
 // dispatcher starts ~2 waves per clock chip-wide, which at one short walk per wave was a fifth of the kernel's time.
-template <int PNORM, int PROC, int ALLOC>
+// A wave keeps its block's (row, column) in the block grid and steps it by 4 columns: the two integer divisions per
+// block that `blk / nbc`, `blk % nbc` cost were 45 of the ~260 scalar instructions of a three-step block.
+__device__ __forceinline__ void next_block(int& brow, int& bcol, int nbc)
+{
+    bcol += 4;
+    while (bcol >= nbc) { bcol -= nbc; ++brow; }                // nbc >= 4: at most once
+}
+
+template <int PNORM, int PROC, bool FITS, int ALLOC>
 __device__ __forceinline__ void walk16_workgroup(const WalkDev& d, uint32_t (&win_all)[4][ALLOC])
 {
     constexpr bool DIA = PROC == GME_SEARCH_DIAMOND;
+    constexpr int PRE = walk_pre<PROC, FITS>(), NW = PRE == 1 ? Win<false>::SEGS_LANE : PRE == 2 ? Win<true>::SEGS_LANE : 1;
+    static_assert(!FITS || (!DIA && WALK_BIG), "FITS is a property of the 48 x 64 window");
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nblk = d.nbr * d.nbc;
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b serves pair
@@ -672,35 +749,42 @@ __device__ __forceinline__ void walk16_workgroup(const WalkDev& d, uint32_t (&wi
     if (pair >= d.pairs) return;                               // wave-uniform
     if (base >= nblk) return;
     // two prefetch buffers used in turn (the loop is unrolled by two so that no registers are copied around)
-    WalkPre pa, pb;
-    walk_prefetch<DIA>(pa, d, pair, base);
+    WalkPre<NW> pa, pb;
+    int ra = base / d.nbc, ca = base - ra * d.nbc, rb, cb;     // block-grid position of pa's block, pb's block
+    walk_prefetch<PRE>(pa, d, pair, ra, ca);
     for (int i = 0; i < d.bpw; i += 2) {
         const int blk = base + 4 * i;                               // valid: checked before it was fetched
         const bool more1 = i + 1 < d.bpw && blk + 4 < nblk;
-        if (more1) walk_prefetch<DIA>(pb, d, pair, blk + 4);         // in flight during this block's walk
-        walk_block<PNORM, PROC>(d, pair, blk, nblk, win_all[wave_in_wg], pa);
+        rb = ra; cb = ca; next_block(rb, cb, d.nbc);
+        walk_block<PNORM, PROC, FITS>(d, pair, blk, ra, ca, nblk, win_all[wave_in_wg], pa, pb, more1, rb, cb);
         if (!more1) break;
         const bool more2 = i + 2 < d.bpw && blk + 8 < nblk;
-        if (more2) walk_prefetch<DIA>(pa, d, pair, blk + 8);
-        walk_block<PNORM, PROC>(d, pair, blk + 4, nblk, win_all[wave_in_wg], pb);
+        ra = rb; ca = cb; next_block(ra, ca, d.nbc);
+        walk_block<PNORM, PROC, FITS>(d, pair, blk + 4, rb, cb, nblk, win_all[wave_in_wg], pb, pa, more2, ra, ca);
         if (!more2) break;
     }
 }
 
 // The diamond instance is held to 64 VGPRs (8 waves per SIMD cover its LDS -> dot4 -> DPP -> v_readlane -> scalar chain);
-// three-step and 2-D log fit 8 waves anyway, and without the cap their scalar state needs no spill (81 / 78 SGPRs).
+// three-step and 2-D log fit 8 waves anyway, and without the cap their scalar state needs no spill.
 template <int PNORM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_walk16(WalkDev d)
 {
     __shared__ uint32_t win_all[4][WIN_ALLOC];
-    walk16_workgroup<PNORM, GME_SEARCH_DIAMOND, WIN_ALLOC>(d, win_all);
+    walk16_workgroup<PNORM, GME_SEARCH_DIAMOND, false, WIN_ALLOC>(d, win_all);
 }
 
-template <int PNORM, int PROC>
-__global__ void __launch_bounds__(256) k_walk16s(WalkDev d)
+// waves per SIMD the register allocation aims at: 8, or 6 for an instance that holds a prefetched window (80 VGPRs)
+#ifndef WALK16S_WAVES_PRE
+#define WALK16S_WAVES_PRE 6
+#endif
+// FITS: first step (three-step) / sw (2-D log) <= 16 -- every search the pipeline and the benches run; wider searches
+// take the instance with the global-memory path
+template <int PNORM, int PROC, bool FITS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(!(FITS && WALK_BIG) ? 1 : walk_pre<PROC, true>() == 2 ? WALK16S_WAVES_PRE : 8, walk_pre<PROC, FITS && WALK_BIG>() == 2 ? WALK16S_WAVES_PRE : 8))) k_walk16s(WalkDev d)
 {
     __shared__ uint32_t win_all[4][Win<WALK_BIG>::ALLOC];
-    walk16_workgroup<PNORM, PROC, Win<WALK_BIG>::ALLOC>(d, win_all);
+    walk16_workgroup<PNORM, PROC, FITS && WALK_BIG, Win<WALK_BIG>::ALLOC>(d, win_all);
 }
 
 // ---------------------------------------------------------------------------
@@ -791,11 +875,19 @@ int launch_bbme_walk_fast(gme_ctx* ctx, const BbmeJob& job, bool* handled)
             else hipLaunchKernelGGL(k_walk16<1>, dim3(grid), dim3(256), 0, ctx->stream, d);
         } else {
             const bool tss = job.procedure == GME_SEARCH_THREESTEP;
-            plan_note(ctx, 0, "k_walk16s<%d,%d> (%s) grid %u blocks/wave %d", job.pnorm, job.procedure, tss ? "three-step" : "2-D log", (unsigned)grid, d.bpw);
-            if (tss && job.pnorm == 0) hipLaunchKernelGGL((k_walk16s<0, GME_SEARCH_THREESTEP>), dim3(grid), dim3(256), 0, ctx->stream, d);
-            else if (tss) hipLaunchKernelGGL((k_walk16s<1, GME_SEARCH_THREESTEP>), dim3(grid), dim3(256), 0, ctx->stream, d);
-            else if (job.pnorm == 0) hipLaunchKernelGGL((k_walk16s<0, GME_SEARCH_TWODLOG>), dim3(grid), dim3(256), 0, ctx->stream, d);
-            else hipLaunchKernelGGL((k_walk16s<1, GME_SEARCH_TWODLOG>), dim3(grid), dim3(256), 0, ctx->stream, d);
+            // the widest round's span (2 x first step / 2 x sw) must fit the window's 32 rows of slack (Win<true>)
+            const bool fits = WALK_BIG && (tss ? d.st1 : d.sw) <= (Win<true>::ROWS - 16) / 2;
+            plan_note(ctx, 0, "k_walk16s<%d,%d,%s> (%s) grid %u blocks/wave %d", job.pnorm, job.procedure, fits ? "true" : "false", tss ? "three-step" : "2-D log", (unsigned)grid, d.bpw);
+#define LAUNCH_WALK16S(P, S)                                                                                     \
+    do {                                                                                                         \
+        if (fits) hipLaunchKernelGGL((k_walk16s<P, S, true>), dim3(grid), dim3(256), 0, ctx->stream, d);         \
+        else hipLaunchKernelGGL((k_walk16s<P, S, false>), dim3(grid), dim3(256), 0, ctx->stream, d);             \
+    } while (0)
+            if (tss && job.pnorm == 0) LAUNCH_WALK16S(0, GME_SEARCH_THREESTEP);
+            else if (tss) LAUNCH_WALK16S(1, GME_SEARCH_THREESTEP);
+            else if (job.pnorm == 0) LAUNCH_WALK16S(0, GME_SEARCH_TWODLOG);
+            else LAUNCH_WALK16S(1, GME_SEARCH_TWODLOG);
+#undef LAUNCH_WALK16S
         }
     } else if (job.bs == 2 && job.procedure == GME_SEARCH_DIAMOND) {
         const unsigned grid = (unsigned)((total + 255) / 256);

@@ -207,17 +207,17 @@ def test_cli_results_model_and_suggest(golden, native, tmp_path, monkeypatch, ca
 
 @pytest.mark.parametrize("proc,pnorm", [(1, 0), (1, 1), (2, 0), (2, 1)])
 def test_walk_instances_at_bench_size(native, proc, pnorm):
-    """bench.py's tss720 / tdl720: the three-step and 2-D log instances (k_walk16s<PNORM, PROC>, 0 SGPR spills) on 41
-    pairs of 720x480 -- asserted through the launch plan -- every pair against the C oracle; sw 16 and a window (sw 4)
-    whose every step fits the LDS window cache."""
+    """bench.py's tss720 / tdl720: the three-step and 2-D log instances (k_walk16s<PNORM, PROC, FITS>, 0 SGPR spills) on 41
+    pairs of 720x480 -- asserted through the launch plan -- every pair against the C oracle; sw 16 and sw 4 (every round
+    fits the LDS window: the FITS instance, first window fetched ahead) and sw 24 (the instance with the global-memory path)."""
     ctx = native.default_context()
     co = c_oracle()
     seq = native.Sequence(ctx, 42, 480, 720)
     seq.synth(1234, 0)
     frames = [seq.read_frame(i) for i in range(42)]
-    for sw in (16, 4):
+    for sw, fits in ((16, "true"), (4, "true"), (24, "false")):     # FITS: every round fits the 48 x 64 LDS window (first step / sw <= 16)
         seq.bbme(1, 16, sw, proc, pnorm)
-        assert ctx.last_bbme_info()["plan"].startswith("k_walk16s<%d,%d>" % (pnorm, proc)), ctx.last_bbme_info()
+        assert ctx.last_bbme_info()["plan"].startswith("k_walk16s<%d,%d,%s>" % (pnorm, proc, fits)), ctx.last_bbme_info()
         mv = seq.read_mv()
         for p in range(41):
             assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, proc, pnorm)), (sw, p)

@@ -455,7 +455,7 @@ def test_committed_profiles_belong_to_these_kernels():
     sha = bench.kernel_source_sha()
     plans = {"exh720": "k_exh_sea16p<3,5>", "exh720mse": "k_exh_sea16p_mse<3,5>", "exh1080": "k_exh_sea16p<5,7>",
              "exh1080mse": "k_exh_sea16p_mse<5,7>", "gme720": "k_walk16<1>", "gme1080exh": "k_exh_sea16p_mse<5,7>",
-             "tss720": "k_walk16s<1,1>", "tdl720": "k_walk16s<1,2>", "dia720mse": "k_walk16<1>", "dia720": "k_walk16<0>",
+             "tss720": "k_walk16s<1,1,true>", "tdl720": "k_walk16s<1,2,true>", "dia720mse": "k_walk16<1>", "dia720": "k_walk16<0>",
              "gme1080": "k_walk16<1>", "seq1080": "k_walk16<1>", "gme720dev": "k_walk16<1>", "tss_bs4sw2": "k_walkq<4,1>",
              "gme_pan240_bs12fd5": "k_walkq<12,1>"}
     for config, kernel in plans.items():

@@ -18,7 +18,7 @@ FIELDS = {"VGPRs": "vgpr", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spi
 BENCHED = ["k_exh_sea16p<3, 5, 36>", "k_exh_sea16p<5, 7, 38>", "k_exh_sea16p_mse<3, 5, 36>", "k_exh_sea16p_mse<5, 7, 38>",
            "k_exh_redo16<3, false>", "k_exh_redo16<3, true>", "k_exh_redo16<5, false>", "k_exh_redo16<5, true>",
            "k_exh_qsad16<3>", "k_exh_dot16<3>", "k_sqbox16",
-           "k_walk16<0>", "k_walk16<1>", "k_walk16s<1, 1>", "k_walk16s<1, 2>", "k_dense2<1>",
+           "k_walk16<0>", "k_walk16<1>", "k_walk16s<1, 1, true>", "k_walk16s<1, 2, true>", "k_dense2<1>",
            "k_fit_level", "k_compensate16", "k_pyrdown_lds"]
 
 
