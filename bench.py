@@ -65,6 +65,11 @@ CONFIGS = {
     "gme720dev": (480, 720, 16, 2, -1, 1, 1234, "720x480 full multiscale affine GME + compensate + PSNR (BASELINE configs[2]) with the OPT-IN "
                   "device solve (GME_DEVICE_SOLVE=1: 3x3 solves on the device, one host round trip per estimate; parameters within "
                   "rtol 1e-10, everything downstream bit-equal or flagged back to the host path)"),
+    # exhaustive MSE on the other unit: sw 16 takes the matrix cores by default (k_exh_mfma16), sw 32 the vector unit's elimination kernel
+    "exh720mse_vec": (480, 720, 16, 16, 0, 1, 1234, "720x480 synthetic luma, bs=16 sw=16 exhaustive MSE on the vector unit (GME_EXH_MFMA=0: the "
+                      "elimination kernel k_exh_sea16p_mse, the default path until round 4)"),
+    "exh1080mse_mfma": (1080, 1920, 16, 32, 0, 1, 4321, "1920x1080 synthetic luma, bs=16 sw=32 exhaustive MSE on the matrix cores (GME_EXH_MFMA=1: "
+                        "opt-in at this window, content-independent)"),
     # the block sizes the reference itself runs besides 16
     "tss_bs4sw2": (480, 720, 4, 2, 1, 1, 1234, "720x480 synthetic luma, bs=4 sw=2 three-step search MSE: bbme.get_motion_field's own "
                    "defaults (bbme.py:15-18)"),
@@ -73,7 +78,9 @@ CONFIGS = {
                            "(docs/presentation/main.tex:382; golden g9)"),
 }
 # per-config extras: frame content uploaded from the host instead of the synthetic generator, frame distance
-EXTRA = {"gme_pan240_bs12fd5": {"content": "pan240seq", "fd": 5}, "gme720dev": {"env": {"GME_DEVICE_SOLVE": "1"}, "streams": 2}}
+EXTRA = {"gme_pan240_bs12fd5": {"content": "pan240seq", "fd": 5}, "gme720dev": {"env": {"GME_DEVICE_SOLVE": "1"}, "streams": 2},
+         "exh720mse_vec": {"env": {"GME_EXH_MFMA": "0"}}, "exh1080mse_mfma": {"env": {"GME_EXH_MFMA": "1"}}}
+INT8_MFMA_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: dense bf16 ~2.5 PF, i8 = 2x bf16 per clock (v_mfma_i32_16x16x64_i8: 32768 ops / 16 cycles / SIMD)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # measured on MI355X (tools/microbench/valu_rates2.hip, profiles/r01_valu_rates.txt):
 # v_qsad_pk_u16_u8 issues one wave-instruction (64 lanes x 16 byte-abs-diffs) per ~16.3
@@ -83,14 +90,16 @@ PARITY_BUDGET_S = 25.0           # C-oracle time the parity gate may spend per b
 # rough C-oracle seconds per pair (one core), to size the parity sample
 ORACLE_S_PER_PAIR = {"exh720": 0.05, "exh720mse": 0.06, "exh1080": 1.3, "exh1080mse": 1.8, "dia720": 0.01,
                      "dia720mse": 0.01, "tss720": 0.01, "tdl720": 0.01, "gme720": 0.03, "gme1080": 0.15, "seq1080": 0.15,
-                     "gme1080exh": 2.1, "tss_bs4sw2": 0.02, "gme_pan240_bs12fd5": 0.01, "gme720dev": 0.03}
+                     "gme1080exh": 2.1, "tss_bs4sw2": 0.02, "gme_pan240_bs12fd5": 0.01, "gme720dev": 0.03,
+                     "exh720mse_vec": 0.06, "exh1080mse_mfma": 1.8}
 # the default line's "secondary" block: (config, pairs per step, steps, warmup, wall seconds of C-oracle parity on
 # ORACLE_THREADS threads, pairs the parity gate checks at least).  seq1080 = BASELINE configs[4] at N = 1: the whole
 # 2000-frame video, with the world-1 RCCL all-gather (gme_shard_gather) inside every step.
-SECONDARY = [("gme720", 2048, 20, 3, 1.0, 8), ("gme720dev", 2048, 20, 3, 1.0, 8), ("exh720mse", 2048, 12, 3, 1.0, 8), ("dia720mse", 2048, 20, 3, 0.5, 8),
+SECONDARY = [("gme720", 2048, 20, 3, 1.0, 8), ("gme720dev", 2048, 20, 3, 1.0, 8), ("exh720mse", 2048, 12, 3, 1.0, 8), ("exh720mse_vec", 2048, 12, 3, 1.0, 8),
+             ("dia720mse", 2048, 20, 3, 0.5, 8),
              ("tss720", 2048, 20, 3, 0.5, 8), ("tdl720", 2048, 20, 3, 0.5, 8),
              ("tss_bs4sw2", 2048, 20, 3, 0.5, 8), ("gme_pan240_bs12fd5", 2048, 20, 3, 0.5, 8),
-             ("exh1080mse", 512, 8, 2, 3.0, 8), ("gme1080exh", 512, 8, 2, 3.5, 8), ("seq1080", None, 8, 2, 2.0, 8)]
+             ("exh1080mse", 512, 8, 2, 3.0, 8), ("exh1080mse_mfma", 512, 8, 2, 3.0, 8), ("gme1080exh", 512, 8, 2, 3.5, 8), ("seq1080", None, 8, 2, 2.0, 8)]
 
 
 def algorithmic_bytes(H, W, bs, gme=False):
@@ -815,7 +824,7 @@ def measure(opt, ctx, comm, rank, world):
     if proc == 0 and world == 1 and opt.content == "synthetic" and opt.content_sweep:
         def sweep_of(pn, kinds):
             sweep = {}
-            nsw = min(B, 512)
+            nsw = B if H * W <= 720 * 480 else min(B, 512)      # the headline's own batch (rounds 2-3 swept 512 pairs: 6-7 % lower rates)
             for kind in kinds:
                 if kind in ("race", "pan240x2") and (H, W) != (480, 720):
                     continue
@@ -946,6 +955,20 @@ def measure(opt, ctx, comm, rank, world):
             out["cpu_baseline_c"] = {"value": 1.0 / t_c, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                      "sample": "oracle/gme_oracle.c (integer C, gcc -O3) on the whole pair t=0,1 in %.2f s" % t_c,
                                      "matches_gpu": bool(np.array_equal(mf_c, seq.read_mv(0, 1)[0]))}
+    if not gme and info.get("plan", "").startswith("k_exh_mfma16"):
+        # the matrix-core search: the roofline that binds is the int8 MFMA rate, not HBM.  ALGORITHMIC ops = 2 x 256 byte
+        # products per valid candidate (the kernel issues about twice that: Toeplitz operands carry zeros, tiles are padded)
+        NT = (2 * sw + 16) // 16
+        hbm = dict(out["roofline"])
+        ops = 2.0 * byte_ops_per_pair(H, W, bs, sw) * B
+        issued = 2.0 * 16 * 16 * 64 * (NT * NT * 8) * (H // 16) * (W // 16) * B
+        out["roofline"] = {"bound": "mfma", "achieved": ops / (kernel_ms * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                           "frac": ops / (kernel_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS, "traffic": hbm.get("traffic"),
+                           "traffic_source": hbm.get("traffic_source"), "kernel": hbm["kernel"], "kernel_ms_per_launch": kernel_ms,
+                           "algorithmic_ops_per_launch": ops, "issued_mfma_ops_per_launch": issued,
+                           "issued_frac": issued / (kernel_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+                           "note": "kernel_ms_per_launch spans the step's two kernels (k_sqbox16 table + k_exh_mfma16); v_mfma_i32_16x16x64_i8, exact int32 sums",
+                           "hbm": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}}
     release()
     return out
 
@@ -979,7 +1002,7 @@ def secondary_block(ctx, comm):
         entry = {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "ms_per_step": d["ms_per_step"],
                  "pairs_per_step": d["config"]["pairs_per_step_per_gpu"], "steps": steps, "warmup": warmup, "streams": d["config"]["streams_per_gpu"],
                  "kernel": d["roofline"]["kernel"], "kernel_ms_per_launch": d["roofline"]["kernel_ms_per_launch"],
-                 "hbm_frac_of_dominant_kernel": d["roofline"]["frac"],
+                 "hbm_frac_of_dominant_kernel": d["roofline"].get("hbm", d["roofline"])["frac"],
                  "parity_ok": d["parity"]["ok"], "pairs_checked_vs_c_oracle": d["parity"]["pairs_checked"],
                  "first_and_last_pair_checked": [d["parity"]["first"], d["parity"]["last"]],
                  "collective": d["config"]["collective"], "seconds": round(time.perf_counter() - t1, 1)}
@@ -987,6 +1010,8 @@ def secondary_block(ctx, comm):
             entry["whole_step_hbm_frac"] = d["roofline"]["whole_step"]["frac"]
         if "elimination" in d:
             entry["surviving_fraction"] = d["elimination"]["surviving_fraction"]
+        if d["roofline"]["bound"] == "mfma":
+            entry["int8_mfma_frac"] = d["roofline"]["frac"]
         block[name] = entry
     block["seconds"] = round(time.perf_counter() - t0, 1)
     return block

@@ -462,21 +462,29 @@ __global__ void __launch_bounds__(1024, (MSE && (R == 4 || (R == 5 && REDO_KS5 =
 #endif
 constexpr int SQ_CHUNK = SQ_CHUNK_ROWS;
 
+// SGN: the squares of (b - 128) instead of b -- the table of the MFMA search (bbme_mfma.hip), whose int8 operands are
+// the frames' bytes with the top bit flipped
+template <bool SGN>
 __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch)
 {
     const uint32_t* p = (const uint32_t*)row;
     uint32_t w[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) w[j] = (x + 4 * j < pitch) ? p[j] : 0u;     // last dword may lie past the pitch
-    uint32_t r[4];
+    // SGN: sum (b - 128)^2 = sum b^2 - 256 sum b + 16 * 16384 per 16 bytes, both sums by v_dot4_u32_u8 (the signed dot
+    // product, v_dot4c_i32_i8, ran this kernel at half the speed: 1.84 against 0.87 ms per 2049 frames of 720x480)
+    uint32_t r[4], sb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        r[e] = 0;
+        r[e] = SGN ? 16u * 16384u : 0u;
+        sb[e] = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t v = e == 0 ? w[j] : __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)e);
             r[e] = __builtin_amdgcn_udot4(v, v, r[e], false);
+            if (SGN) sb[e] = __builtin_amdgcn_udot4(v, 0x01010101u, sb[e], false);
         }
+        if (SGN) r[e] -= 256u * sb[e];
     }
     u32x4_v out;
     out.x = r[0]; out.y = r[1]; out.z = r[2]; out.w = r[3];          // columns beyond W-16 are never read
@@ -489,6 +497,7 @@ __device__ __forceinline__ u32x4_v sq_hsum4(const uint8_t* row, int x, int pitch
 // work of a kernel that was 26 % VALU-busy, a quarter of the registers.
 // (Round 4 tried the ring in LDS -- 16 x 16 bytes per thread, 64 KiB per workgroup, minimum traffic: 2 waves per SIMD are too
 // few for a streaming kernel, exhaustive MSE 328 k -> 291 k pairs/s, same box.)
+template <bool SGN>
 __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long src_stride, int H, int W, int pitch,
                                                  uint32_t* dst, long long dst_stride)
 {
@@ -499,12 +508,12 @@ __global__ void __launch_bounds__(256) k_sqbox16(const uint8_t* src, long long s
     uint32_t* o = dst + (long long)blockIdx.z * dst_stride + (long long)y0 * pitch + x;
     u32x4_v s = { 0, 0, 0, 0 };
 #pragma unroll 5
-    for (int r = 0; r < 15; ++r) s += sq_hsum4(p + (long long)r * pitch, x, pitch);        // rows y0 .. y0+14 <= H-2
+    for (int r = 0; r < 15; ++r) s += sq_hsum4<SGN>(p + (long long)r * pitch, x, pitch);        // rows y0 .. y0+14 <= H-2
     const int last = min(SQ_CHUNK - 1, H - 16 - y0);     // last output row of this chunk
 #pragma unroll 2
     for (int k = 0; k <= last; ++k) {
-        const u32x4_v hn = sq_hsum4(p + (long long)(k + 15) * pitch, x, pitch);            // row y0+k+15 <= H-1 enters
-        const u32x4_v ho = sq_hsum4(p + (long long)k * pitch, x, pitch);                   // row y0+k leaves behind this output
+        const u32x4_v hn = sq_hsum4<SGN>(p + (long long)(k + 15) * pitch, x, pitch);            // row y0+k+15 <= H-1 enters
+        const u32x4_v ho = sq_hsum4<SGN>(p + (long long)k * pitch, x, pitch);                   // row y0+k leaves behind this output
         s += hn;
         // non-temporal: the 4-byte-per-pixel output stream would otherwise push the source rows out of the L2 before
         // their second read 16 rows later (same box: 315.2 k -> 319.3 k pairs/s exhaustive MSE, 30.45 k -> 30.8 k at 1080p)
@@ -640,7 +649,7 @@ int launch_exh_redo(gme_ctx* ctx, const BbmeJob& job, int R, int tr, int tc, int
 // 16x16 box sums of squares for `count` planes: `out` is a uint32 stack with the frame's pitch
 // (elements) and `stride` elements between planes.
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
-                   uint32_t* out, long long stride)
+                   uint32_t* out, long long stride, bool sgn)
 {
     if (count == 0 || H < 16 || W < 16) return GME_OK;
     const int step = max_grid_planes();
@@ -648,8 +657,10 @@ int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int c
         const int n = count - first < step ? count - first : step;
         const int xq = (W - 16) / 4 + 1;                            // column quads that hold a valid position
         const dim3 g((xq + 63) / 64, ((H - 15 + SQ_CHUNK - 1) / SQ_CHUNK + 3) / 4, n);
-        hipLaunchKernelGGL(k_sqbox16, g, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W, pitch,
-                           out + first * stride, stride);
+        if (sgn) hipLaunchKernelGGL(k_sqbox16<true>, g, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W, pitch,
+                                    out + first * stride, stride);
+        else hipLaunchKernelGGL(k_sqbox16<false>, g, dim3(256), 0, ctx->stream, src + first * src_stride, src_stride, H, W, pitch,
+                                out + first * stride, stride);
     }
     GME_HIP_TRY(hipGetLastError());
     return GME_OK;
@@ -660,12 +671,13 @@ int bbme_aux_kind(int bs, int sw, int procedure, int pnorm)
     if (procedure != GME_SEARCH_EXHAUSTIVE || bs != 16 || pnorm != GME_NORM_MSE) return 0;
     if (sw < 0 || sw % 4 != 0) return 0;
     const int NC = 2 * sw + 16;
-    return ((NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC")) ? 1 : 0;
+    if (!((NC + 15) / 16 <= 5 && NC * NC <= 8192 && !getenv("GME_FORCE_GENERIC"))) return 0;
+    return bbme_mfma_wanted(sw) ? 2 : 1;
 }
 
 int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
                      int pitch, uint32_t* out, long long stride)
 {
-    if (kind == 1) return launch_sqbox16(ctx, src, src_stride, count, H, W, pitch, out, stride);
+    if (kind == 1 || kind == 2) return launch_sqbox16(ctx, src, src_stride, count, H, W, pitch, out, stride, kind == 2);
     return GME_OK;
 }

@@ -556,6 +556,8 @@ static int launch_bbme_chunk(gme_ctx* ctx, const BbmeJob& job)
     GME_REQUIRE(nblk * job.pairs < (1ll << 31) / 64, GME_ERR_ARG, "too many blocks in one launch");
 
     bool handled = false;
+    rc = launch_bbme_mfma(ctx, job, &handled);              // exhaustive MSE at bs 16: the correlation on the matrix cores
+    if (rc != GME_OK || handled) return rc;
     rc = launch_bbme_sea(ctx, job, &handled);
     if (rc != GME_OK || handled) return rc;
     rc = launch_bbme_sea_mse(ctx, job, &handled);

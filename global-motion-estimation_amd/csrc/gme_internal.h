@@ -200,13 +200,17 @@ __device__ __forceinline__ void sq4(SqTable t, long long idx, uint32_t (&out)[4]
 }
 #endif
 int launch_sqbox16(gme_ctx* ctx, const uint8_t* src, long long src_stride, int count, int H, int W, int pitch,
-                   uint32_t* tmp, uint32_t* out, long long stride);
+                   uint32_t* out, long long stride, bool sgn);
 // per-frame auxiliary table a fast exhaustive kernel wants for `cur` (BbmeJob::sqbox_cur):
-// 0 none, 1 = 16x16 box sums of squares (MSE, k_exh_dot16)
+// 0 none, 1 = 16x16 box sums of squares (MSE, k_exh_dot16 and the elimination kernels), 2 = 16x16 box sums of the squares
+// of (byte - 128) (MSE on the matrix cores, bbme_mfma.hip)
 int bbme_aux_kind(int bs, int sw, int procedure, int pnorm);
 int launch_aux_table(gme_ctx* ctx, int kind, const uint8_t* src, long long src_stride, int count, int H, int W,
                      int pitch, uint32_t* out, long long stride);
 bool bbme_sea_applies(int bs, int sw, int procedure, int pnorm);
+// ---- bbme_mfma.hip: exhaustive MSE at bs 16 as an int8 correlation on the matrix cores
+bool bbme_mfma_wanted(int sw);                // search windows it takes (and GME_EXH_MFMA has not switched it off)
+int launch_bbme_mfma(gme_ctx* ctx, const BbmeJob& job, bool* handled);
 
 int bbme_check_args(int H, int W, int bs, int sw, int procedure, int pnorm);
 

@@ -401,6 +401,7 @@ def test_sea_schedules_agree(mods, monkeypatch, mode):
     block rows, pair counts that are not a multiple of the 8 XCDs, every window size class, both norms."""
     native, bbme, _, _ = mods
     monkeypatch.setenv("GME_SEA_PERSIST", mode)
+    monkeypatch.setenv("GME_EXH_MFMA", "0")          # MSE at sw <= 16 would otherwise take the matrix-core kernel
     ctx = native.default_context()
     co = c_oracle()
     for (n, h, w, sw, seed) in ((12, 96, 176, 16, 3), (4, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6),

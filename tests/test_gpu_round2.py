@@ -50,7 +50,12 @@ def test_benched_instance_720_every_pair(native, pnorm):
     co = c_oracle()
     seq = native.Sequence(ctx, 68, 480, 720)
     seq.synth(1234, 0)
-    seq.bbme(1, 16, 16, 0, pnorm)
+    if pnorm == 1:          # the default MSE path at sw 16 is the matrix-core kernel (tests/test_gpu_mfma.py); this test holds the
+        os.environ["GME_EXH_MFMA"] = "0"         # vector-unit elimination instance to the same bar
+    try:
+        seq.bbme(1, 16, 16, 0, pnorm)
+    finally:
+        os.environ.pop("GME_EXH_MFMA", None)
     info = ctx.last_bbme_info()
     assert info["plan"].startswith("k_exh_sea16p%s<3," % ("_mse" if pnorm else "")), info
     assert "persistent-dynamic" in info["plan"] and "tiles 2x4" in info["plan"], info
@@ -70,6 +75,7 @@ def test_benched_instance_720_hostile_content(native, kind, monkeypatch):
     (mixed), both norms, every pair against the C oracle -- with and without the redo path."""
     ctx = native.default_context()
     co = c_oracle()
+    monkeypatch.setenv("GME_EXH_MFMA", "0")          # the elimination + redo path under both norms (MSE's default at sw 16 is k_exh_mfma16)
     rng = np.random.default_rng(7 + len(kind))
     frames = _contents(kind, 22, 480, 720, rng)
     seq = native.Sequence.from_frames(ctx, frames)
@@ -100,6 +106,7 @@ def test_redo_path_small_batches_and_window_sizes(native, monkeypatch):
     ctx = native.default_context()
     co = c_oracle()
     monkeypatch.setenv("GME_SEA_REDO_FRAC", "0")
+    monkeypatch.setenv("GME_EXH_MFMA", "0")
     for persist in ("0", "2"):
         monkeypatch.setenv("GME_SEA_PERSIST", persist)
         for (n, h, w, sw, seed) in ((5, 96, 176, 16, 3), (3, 70, 330, 8, 4), (10, 50, 66, 4, 5), (3, 130, 150, 32, 6), (4, 80, 112, 24, 7)):

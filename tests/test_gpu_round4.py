@@ -98,8 +98,19 @@ def test_pan240x2_every_pair_vs_oracle(native, pnorm):
     co = c_oracle()
     seq = native.Sequence.from_frames(ctx, frames)
     try:
-        seq.bbme(1, 16, 16, 0, pnorm)
+        if pnorm == 1:                            # default path of MSE at sw 16: the matrix-core kernel, every pair as well
+            seq.bbme(1, 16, 16, 0, 1)
+            assert ctx.last_bbme_info()["plan"].startswith("k_exh_mfma16<3>"), ctx.last_bbme_info()
+            mfma = seq.read_mv().copy()
+            os.environ["GME_EXH_MFMA"] = "0"
+            seq.invalidate_pyramids()
+        try:
+            seq.bbme(1, 16, 16, 0, pnorm)
+        finally:
+            os.environ.pop("GME_EXH_MFMA", None)
         mv = seq.read_mv()
+        if pnorm == 1:
+            assert np.array_equal(mv, mfma)
         info = ctx.last_bbme_info()
         assert info["plan"].startswith("k_exh_sea16p" + ("_mse" if pnorm else "") + "<3,"), info
         want = bench.oracle_map(lambda p: co.bbme(frames[p], frames[p + 1], 16, 16, 0, pnorm), list(range(50)))

@@ -453,7 +453,8 @@ def test_committed_profiles_belong_to_these_kernels():
     sys.path.insert(0, REPO)
     import bench
     sha = bench.kernel_source_sha()
-    plans = {"exh720": "k_exh_sea16p<3,5>", "exh720mse": "k_exh_sea16p_mse<3,5>", "exh1080": "k_exh_sea16p<5,7>",
+    plans = {"exh720": "k_exh_sea16p<3,5>", "exh720mse": "k_exh_mfma16<3,3,4>", "exh720mse_vec": "k_exh_sea16p_mse<3,5>", "exh1080": "k_exh_sea16p<5,7>",
+             "exh1080mse_mfma": "k_exh_mfma16<5,2,4>",
              "exh1080mse": "k_exh_sea16p_mse<5,7>", "gme720": "k_walk16<1>", "gme1080exh": "k_exh_sea16p_mse<5,7>",
              "tss720": "k_walk16s<1,1,true>", "tdl720": "k_walk16s<1,2,true>", "dia720mse": "k_walk16<1>", "dia720": "k_walk16<0>",
              "gme1080": "k_walk16<1>", "seq1080": "k_walk16<1>", "gme720dev": "k_walk16<1>", "tss_bs4sw2": "k_walkq<4,1>",
@@ -484,6 +485,8 @@ def test_benched_kernel_instances_do_not_spill():
             assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (r["name"], r)
     # what the launch bounds promise: 8 waves per SIMD for the R = 3 elimination kernels and the walk searches, >= 5 for the
     # 720x480 hostile-content MSE body (round 3 claimed 5 and had 4)
+    m3 = rows["k_exh_mfma16<3, 3, 4>"]              # its speed hangs on waves per SIMD: VGPRs + AGPRs (the accumulators) of the unified file
+    assert m3["vgpr"] + m3["agpr"] <= 128 and m3["waves"] >= 4, m3
     for name, waves in (("k_exh_sea16p<3, 5, 36>", 8), ("k_exh_sea16p_mse<3, 5, 36>", 8), ("k_walk16<1>", 8), ("k_exh_redo16<3, true>", 5),
                         ("k_exh_sea16p<5, 7, 38>", 6), ("k_exh_sea16p_mse<5, 7, 38>", 6), ("k_exh_redo16<5, true>", 4)):
         assert rows[name]["waves"] >= waves, (name, rows[name])

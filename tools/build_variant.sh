@@ -9,7 +9,7 @@ B=/tmp/gme_variant_$NAME; mkdir -p $B
 SRC=global-motion-estimation_amd/csrc
 CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -Wno-unused-value $FLAGS"
 pids=""
-for f in gme_api gme_comm bbme_kernels bbme_fast bbme_sea bbme_sea_mse bbme_walk16 gme_kernels synth_kernels; do
+for f in gme_api gme_comm bbme_kernels bbme_fast bbme_sea bbme_sea_mse bbme_mfma bbme_walk16 gme_kernels synth_kernels; do
   $CXX -c $SRC/$f.hip -o $B/$f.o & pids="$pids $!"
 done
 for p in $pids; do wait $p; done

@@ -2,9 +2,9 @@
 #   bash tools/final_run.sh <tag> tests      GPU tests, the default bench line (with secondary block, sweeps, CPU baseline), rehearsals, scale_run
 #   bash tools/final_run.sh <tag> benches    one bench line per config (CPU baseline included) + hostile / real content lines
 #   bash tools/final_run.sh <tag> prof "<config:kernel-substring> ..."     tools/profile_configs.sh (bench + rocprofv3 kernel stats + PMC passes)
-#       round 4: "exh720:k_ exh720mse:k_ gme720:k_ tss720:k_ tdl720:k_ dia720mse:k_ exh1080:k_ exh1080mse:k_ gme1080exh:k_" (12.5 GPU-minutes)
-#       and "seq1080:k_ gme1080:k_ dia720:k_ tss_bs4sw2:k_ gme_pan240_bs12fd5:k_ gme720dev:k_" (4); tests/test_host.py checks that they belong to
-#       the committed kernels
+#       round 4: "exh720:k_ exh720mse:k_ exh720mse_vec:k_ gme720:k_ tss720:k_ tdl720:k_ dia720mse:k_ exh1080:k_ exh1080mse:k_ gme1080exh:k_" (8.5 GPU-minutes)
+#       and "seq1080:k_ gme1080:k_ dia720:k_ tss_bs4sw2:k_ gme_pan240_bs12fd5:k_ gme720dev:k_ exh1080mse_mfma:k_" (5); tests/test_host.py checks that
+#       they belong to the committed kernels
 # Copy gpurun_out/<tag>/*_{bench.json,kernel_stats.csv,pmc_summary.txt} into profiles/ afterwards (tools/collect_profiles.sh).
 TAG=${1:-r04_final}; PART=${2:-tests}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
@@ -53,7 +53,7 @@ PY
   bash tools/rccl_dup_rehearsal.sh $O/rccl_dup 2>&1 | head -14
   bash tools/scale_run.sh exh720 20 3 $O/scale 2>&1 | tail -3
 elif [ "$PART" = benches ]; then
-  for c in exh720mse exh1080 exh1080mse dia720 dia720mse tss720 tdl720 gme720 gme720dev gme1080 gme1080exh seq1080 tss_bs4sw2 gme_pan240_bs12fd5; do
+  for c in exh720mse exh720mse_vec exh1080 exh1080mse exh1080mse_mfma dia720 dia720mse tss720 tdl720 gme720 gme720dev gme1080 gme1080exh seq1080 tss_bs4sw2 gme_pan240_bs12fd5; do
     timeout -k 10 400 python3 bench.py --config $c --no-secondary 2>$O/${c}_bench.err > $O/${TAG}_${c}_bench.json || { echo "$c failed"; tail -3 $O/${c}_bench.err; continue; }
     line $c $O/${TAG}_${c}_bench.json
   done
@@ -62,7 +62,7 @@ elif [ "$PART" = benches ]; then
   GME_BENCH_STREAMS=1 GME_DEVICE_SOLVE=1 timeout -k 10 300 python3 bench.py --config gme720 --no-secondary --no-cpu-baseline --no-pcie 2>/dev/null > $O/${TAG}_gme720_1stream_devsolve_bench.json; line gme720_1stream_devsolve $O/${TAG}_gme720_1stream_devsolve_bench.json
   GME_SEA_QUOTA=0 timeout -k 10 300 python3 bench.py --content pan240x2 --no-secondary --no-cpu-baseline --no-pcie --no-content-sweep 2>/dev/null > $O/${TAG}_exh720_pan240x2_noc2_bench.json; line exh720_pan240x2_noc2 $O/${TAG}_exh720_pan240x2_noc2_bench.json
   for c in noise flat race pan240x2 pan240seq; do
-    for cfg in exh720 exh720mse; do
+    for cfg in exh720 exh720mse exh720mse_vec; do
       timeout -k 10 300 python3 bench.py --config $cfg --content $c --no-secondary --no-cpu-baseline --no-pcie 2>/dev/null > $O/${TAG}_${cfg}_${c}_bench.json; line ${cfg}_$c $O/${TAG}_${cfg}_${c}_bench.json
     done
   done

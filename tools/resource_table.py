@@ -12,12 +12,12 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(REPO, "global-motion-estimation_amd", "csrc", "build")
-FIELDS = {"VGPRs": "vgpr", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill", "ScratchSize [bytes/lane]": "scratch",
+FIELDS = {"VGPRs": "vgpr", "AGPRs": "agpr", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill", "ScratchSize [bytes/lane]": "scratch",
           "Occupancy [waves/SIMD]": "waves", "LDS Size [bytes/block]": "lds"}
 # the instances bench.py's configs launch (launch plans of DESIGN.md section 5), in the table's order
 BENCHED = ["k_exh_sea16p<3, 5, 36>", "k_exh_sea16p<5, 7, 38>", "k_exh_sea16p_mse<3, 5, 36>", "k_exh_sea16p_mse<5, 7, 38>",
            "k_exh_redo16<3, false>", "k_exh_redo16<3, true>", "k_exh_redo16<5, false>", "k_exh_redo16<5, true>",
-           "k_exh_qsad16<3>", "k_exh_dot16<3>", "k_sqbox16",
+           "k_exh_mfma16<3, 3, 4>", "k_exh_mfma16<5, 2, 4>", "k_exh_qsad16<3>", "k_exh_dot16<3>", "k_sqbox16",
            "k_walk16<0>", "k_walk16<1>", "k_walk16s<1, 1, true>", "k_walk16s<1, 2, true>", "k_dense2<1>",
            "k_fit_level", "k_compensate16", "k_pyrdown_lds"]
 
@@ -57,13 +57,13 @@ def table(rows, only_benched=True):
     for r in rows:
         by.setdefault(r["name"], r)
     names = [n for n in BENCHED if any(k == n or k.startswith(n + "<") or k.startswith(n) and n in ("k_fit_level", "k_compensate16", "k_pyrdown_lds", "k_sqbox16") for k in by)] if only_benched else sorted(by)
-    lines = ["| kernel instance | file | VGPRs | VGPR spills | SGPR spills | scratch B/lane | waves/SIMD |", "|---|---|---|---|---|---|---|"]
+    lines = ["| kernel instance | file | VGPRs | AGPRs | VGPR spills | SGPR spills | scratch B/lane | waves/SIMD |", "|---|---|---|---|---|---|---|---|"]
     for n in names:
         cands = [k for k in by if k == n or (n in ("k_fit_level", "k_compensate16", "k_pyrdown_lds", "k_sqbox16") and k.startswith(n))]
         for k in sorted(cands):
             r = by[k]
-            lines.append("| `%s` | %s | %d | %d | %d | %d | %d |" % (k, r["file"], r.get("vgpr", -1), r.get("vgpr_spill", -1), r.get("sgpr_spill", -1),
-                                                                  r.get("scratch", -1), r.get("waves", -1)))
+            lines.append("| `%s` | %s | %d | %d | %d | %d | %d | %d |" % (k, r["file"], r.get("vgpr", -1), r.get("agpr", 0), r.get("vgpr_spill", -1),
+                                                                       r.get("sgpr_spill", -1), r.get("scratch", -1), r.get("waves", -1)))
     return "\n".join(lines)
 
 
