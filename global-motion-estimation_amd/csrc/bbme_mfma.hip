@@ -56,8 +56,15 @@
 #ifndef MFMA_BOP_PREFETCH
 #define MFMA_BOP_PREFETCH 0
 #endif
+// Waves per SIMD decide this kernel (the unified file holds VGPRs + AGPRs; the accumulators live in AGPRs).  At sw <= 16:
+// window operands single-buffered and the accumulator tiles pinned by an empty asm after every step -> 45 + 48 registers =
+// 5 waves (double-buffered, unpinned: 77 + 48 = 4 waves; same box 415.4 k -> 429.1 k pairs/s).  At sw 32 neither form gets
+// under the 128 registers of 4 waves and double buffering is worth 5 % (32.7 k against 31.1 k): -1 = that choice by NT.
+#ifndef MFMA_PIN_ACC
+#define MFMA_PIN_ACC -1
+#endif
 #ifndef MFMA_WQ_DOUBLE
-#define MFMA_WQ_DOUBLE 1
+#define MFMA_WQ_DOUBLE -1
 #endif
 #ifndef MFMA_STAGE_PREFETCH
 #define MFMA_STAGE_PREFETCH 1
@@ -163,6 +170,8 @@ __device__ __forceinline__ void mfma_pass(const MfmaBlock& k, const __amdgpu_buf
     };
     if (MFMA_EARLY_TABLE) table_reads(0, tb[0]);
     constexpr int STEPS = 4 * NT;
+    constexpr bool WQ_DOUBLE = MFMA_WQ_DOUBLE < 0 ? NT > 3 : MFMA_WQ_DOUBLE != 0;
+    constexpr bool PIN_ACC = MFMA_PIN_ACC < 0 ? NT <= 3 : MFMA_PIN_ACC != 0;
     v4i acc[NT][TXN];
 #pragma unroll
     for (int ty = 0; ty < NT; ++ty)
@@ -170,7 +179,7 @@ __device__ __forceinline__ void mfma_pass(const MfmaBlock& k, const __amdgpu_buf
         for (int tx = 0; tx < TXN; ++tx) acc[ty][tx] = v4i{0, 0, 0, 0};
     u32x4 wq[2][TXN + 1];
     const uint8_t* wcol = k.wbase + 16 * TX0;
-    if (MFMA_WQ_DOUBLE) {
+    if (WQ_DOUBLE) {
 #pragma unroll
         for (int xi = 0; xi <= TXN; ++xi) wq[0][xi] = *(const u32x4*)(wcol + 16 * xi);      // step 0: rg 0, ty 0
     }
@@ -181,25 +190,29 @@ __device__ __forceinline__ void mfma_pass(const MfmaBlock& k, const __amdgpu_buf
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const int rg = st / NT, ty = st - rg * NT;
-        if (!MFMA_WQ_DOUBLE) {
+        if (!WQ_DOUBLE) {
             const uint8_t* wrow = wcol + 4 * (4 * ty + rg) * PITCH;
 #pragma unroll
             for (int xi = 0; xi <= TXN; ++xi) wq[st & 1][xi] = *(const u32x4*)(wrow + 16 * xi);
         }
-        if (MFMA_WQ_DOUBLE && st + 1 < STEPS) {
+        if (WQ_DOUBLE && st + 1 < STEPS) {
             const int rg1 = (st + 1) / NT, ty1 = (st + 1) - rg1 * NT;
             const uint8_t* wrow = wcol + 4 * (4 * ty1 + rg1) * PITCH;
 #pragma unroll
             for (int xi = 0; xi <= TXN; ++xi) wq[(st + 1) & 1][xi] = *(const u32x4*)(wrow + 16 * xi);
             if (MFMA_BOP_PREFETCH && ty == 0 && rg + 1 < 4) { bop_read(k, 0, rg + 1, raw[0]); bop_read(k, 1, rg + 1, raw[1]); }
         }
-        if (MFMA_WQ_DOUBLE) __builtin_amdgcn_sched_barrier(0);             // the next step's reads are in flight before this one's MFMAs
+        if (WQ_DOUBLE) __builtin_amdgcn_sched_barrier(0);             // the next step's reads are in flight before this one's MFMAs
 #pragma unroll
         for (int xi = 0; xi <= TXN; ++xi) {
             const u32x4 t = wq[st & 1][xi];
             const v4i wop = { (int)t.x, (int)t.y, (int)t.z, (int)t.w };
             if (xi < TXN) acc[ty][xi] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop, bop[0], acc[ty][xi], 0, 0, 0);
             if (xi >= 1) acc[ty][xi - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop, bop[1], acc[ty][xi - 1], 0, 0, 0);
+        }
+        if (PIN_ACC) {
+#pragma unroll
+            for (int xi = 0; xi < TXN; ++xi) asm volatile("" : "+a"(acc[ty][xi]));
         }
         if (ty == NT - 1 && rg + 1 < 4) {
             if (!MFMA_BOP_PREFETCH) { bop_read(k, 0, rg + 1, raw[0]); bop_read(k, 1, rg + 1, raw[1]); }
@@ -246,10 +259,11 @@ __device__ __forceinline__ void mfma_pass(const MfmaBlock& k, const __amdgpu_buf
 // XS = tile columns per pass: NT x XS x 4 accumulator registers (sw 32: 5 x 3 and 5 x 2 instead of 5 x 5 = 100).
 // A workgroup walks d.rpw consecutive block rows of its tile column: the next row's window and anchors are fetched into
 // registers while the current one is searched (global latency behind the MFMAs, 1 / rpw of the workgroup launches).
-// Registers decide this kernel's speed (latencies are covered by waves, not by one wave's schedule): 78 VGPRs = 6 waves per
-// SIMD at sw 16.  An occupancy attribute does not help -- asked for 5 or 6 waves the scheduler first builds its usual
-// pressure and then spills 33-53 registers; what keeps the count down is in the code: row groups outer (two B operands
-// live), no operand prefetch, the opaque lane indices of the row loop.  tests/test_host.py holds the build to <= 80.
+// Registers decide this kernel's speed (latencies are covered by waves, not by one wave's schedule).  An occupancy
+// attribute does not help -- asked for 5 or 6 waves the scheduler first builds its usual pressure and then spills 33-67
+// registers; what keeps the count down is in the code: row groups outer (two B operands live), no operand prefetch, the
+// opaque lane indices of the row loop, one tile's table reads at a time, pinned accumulators (see MFMA_PIN_ACC).
+// tests/test_host.py holds the sw 16 instance to 5 waves.
 template <int NT, int XS, int TC>
 __global__ void __launch_bounds__(64 * TC) k_exh_mfma16(MfmaDev d)
 {

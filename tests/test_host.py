@@ -486,7 +486,7 @@ def test_benched_kernel_instances_do_not_spill():
     # what the launch bounds promise: 8 waves per SIMD for the R = 3 elimination kernels and the walk searches, >= 5 for the
     # 720x480 hostile-content MSE body (round 3 claimed 5 and had 4)
     m3 = rows["k_exh_mfma16<3, 3, 4>"]              # its speed hangs on waves per SIMD: VGPRs + AGPRs (the accumulators) of the unified file
-    assert m3["vgpr"] + m3["agpr"] <= 128 and m3["waves"] >= 4, m3
+    assert m3["vgpr"] + m3["agpr"] <= 96 and m3["waves"] >= 5, m3
     for name, waves in (("k_exh_sea16p<3, 5, 36>", 8), ("k_exh_sea16p_mse<3, 5, 36>", 8), ("k_walk16<1>", 8), ("k_exh_redo16<3, true>", 5),
                         ("k_exh_sea16p<5, 7, 38>", 6), ("k_exh_sea16p_mse<5, 7, 38>", 6), ("k_exh_redo16<5, true>", 4)):
         assert rows[name]["waves"] >= waves, (name, rows[name])
