@@ -12,13 +12,16 @@ ROWS = [("exh720", "default", "720×480 bs16 sw16 exhaustive MAE (configs[1])"),
         ("exh720_pan240x2", None, "same on pan240 ×2 (51 real frames, 640×480)"), ("exh720_pan240x2_noc2", None, "same, phase C2 off (`GME_SEA_QUOTA=0`)"),
         ("exh720_pan240seq", None, "same on pan240 (51 real frames, 320×240)"), ("exh720_race", None, "same on `race` (2 real frames)"),
         ("exh720_flat", None, "same on flat frames"), ("exh720_noise", None, "same on uniform noise (→ redo kernel)"),
-        ("exh720mse", None, "720×480 exhaustive MSE"), ("exh720mse_pan240x2", None, "same on pan240 ×2"), ("exh720mse_noise", None, "same on uniform noise"),
+        ("exh720mse", None, "720×480 exhaustive MSE (matrix cores)"), ("exh720mse_pan240x2", None, "same on pan240 ×2"), ("exh720mse_noise", None, "same on uniform noise"),
+        ("exh720mse_vec", None, "720×480 exhaustive MSE on the vector unit (`GME_EXH_MFMA=0`)"), ("exh720mse_vec_pan240x2", None, "same on pan240 ×2"),
+        ("exh720mse_vec_noise", None, "same on uniform noise"),
         ("tss720", None, "720×480 three-step MSE"), ("tdl720", None, "720×480 2-D log MSE"), ("dia720", None, "720×480 diamond MAE"),
         ("dia720mse", None, "720×480 diamond MSE"), ("tss_bs4sw2", None, "720×480 three-step bs 4 sw 2 MSE (the reference's default call)"),
         ("gme720", None, "720×480 full GME + compensate + PSNR (configs[2]), 4 ranges"), ("gme720_1stream", None, "same, one stream, blocking calls"),
         ("gme720dev", None, "same, opt-in device solve, 2 ranges"), ("gme720_1stream_devsolve", None, "same, opt-in device solve, one stream"),
         ("gme_pan240_bs12fd5", None, "320×240 real frames, GME at bs 12 / fd 5 (the slides' setting)"),
         ("exh1080", None, "1920×1080 exhaustive MAE sw 32"), ("exh1080mse", None, "1920×1080 exhaustive MSE sw 32 (configs[3] BBME)"),
+        ("exh1080mse_mfma", None, "same on the matrix cores (opt-in, `GME_EXH_MFMA=1`)"),
         ("gme1080exh", None, "1920×1080 exhaustive-MSE GME + compensate (configs[3])"), ("gme1080", None, "1920×1080 diamond GME + compensate"),
         ("seq1080", None, "2000-frame 1080p sequence, diamond GME + gather (configs[4], 1 rank)")]
 
@@ -41,10 +44,12 @@ for name, alias, label in ROWS:
     if d is None:
         continue
     o = load(prev, alias or name) or load(prev, name)
-    kern = d["roofline"]["kernel"].split(" tiles")[0].split(" grid")[0].split(" (")[0]
+    kern = d["roofline"]["kernel"].split(" tiles")[0].split(" grid")[0].split(" (")[0].split(" 1x")[0]
     cpu = d.get("cpu_baseline", {}).get("value")
     e = d.get("elimination")
     extra = " (scored %.2f %%, first UB left %.2f %%)" % (100 * e["surviving_fraction"], 100 * e.get("listed_fraction_before_ordered_rounds", e["surviving_fraction"])) if e else ""
-    print("| %s | `%s` | %s → **%s**%s | %.3f | %.3f | %s | %d / %d |" % (
+    r = d["roofline"]
+    frac = "%.3f" % r.get("hbm", r)["frac"] + (" (int8 MFMA %.3f algorithmic, %.3f issued)" % (r["frac"], r["issued_frac"]) if r["bound"] == "mfma" else "")
+    print("| %s | `%s` | %s → **%s**%s | %.3f | %s | %s | %d / %d |" % (
         label, kern, ("%d" % round(o["value"])) if o else "—", "{:,}".format(round(d["value"])).replace(",", " "), extra, d["ms_per_step"],
-        d["roofline"]["frac"], ("%.4g" % cpu) if cpu else "", d["parity"]["pairs_checked"] - len(d["parity"].get("mismatching_pairs", [])), d["parity"]["pairs_checked"]))
+        frac, ("%.4g" % cpu) if cpu else "", d["parity"]["pairs_checked"] - len(d["parity"].get("mismatching_pairs", [])), d["parity"]["pairs_checked"]))
