@@ -118,15 +118,42 @@ def byte_ops_per_pair(H, W, bs, sw):
     return valid(H) * valid(W) * bs * bs
 
 
-def kernel_source_sha():
-    """Identity of the kernels a committed profile belongs to: sha256 over csrc/ sources."""
+# Which files of csrc/ a config's launches come from (beyond the ones every config depends on): a change in one file only
+# invalidates the committed profiles of the configs listed with it.  bbme_mfma.hip also holds the policy that sends exhaustive
+# MSE to one unit or the other, so it belongs to every exhaustive-MSE config.
+COMMON_SOURCES = ("Makefile", "gme_internal.h", "gme_api.hip", "bbme_kernels.hip", "synth_kernels.hip")
+_SEA = ("bbme_sea_common.h", "bbme_fast.hip")
+_GME = ("gme_kernels.hip", "bbme_walk16.hip")
+CONFIG_SOURCES = {
+    "exh720": ("bbme_sea.hip",) + _SEA, "exh1080": ("bbme_sea.hip",) + _SEA,
+    "exh720mse": ("bbme_mfma.hip", "bbme_fast.hip"), "exh1080mse_mfma": ("bbme_mfma.hip", "bbme_fast.hip"),
+    "exh720mse_vec": ("bbme_sea_mse.hip", "bbme_mfma.hip") + _SEA, "exh1080mse": ("bbme_sea_mse.hip", "bbme_mfma.hip") + _SEA,
+    "gme1080exh": ("bbme_sea_mse.hip", "bbme_mfma.hip") + _SEA + _GME,
+    "gme720": _GME, "gme720dev": _GME, "gme1080": _GME, "gme_pan240_bs12fd5": _GME, "seq1080": _GME + ("gme_comm.hip",),
+    "tss720": ("bbme_walk16.hip",), "tdl720": ("bbme_walk16.hip",), "dia720": ("bbme_walk16.hip",), "dia720mse": ("bbme_walk16.hip",),
+    "tss_bs4sw2": (),
+}
+
+
+def kernel_source_sha(config=None):
+    """Identity of the kernels a committed profile belongs to: sha256 over csrc/ sources -- all of them, or (config given)
+    the files that config's launches are compiled from (CONFIG_SOURCES + COMMON_SOURCES)."""
     h = hashlib.sha256()
     root = os.path.join(REPO, "global-motion-estimation_amd", "csrc")
+    only = None if config is None else set(COMMON_SOURCES) | set(CONFIG_SOURCES[config])
     for name in sorted(os.listdir(root)):
-        if name.endswith((".hip", ".h")) or name == "Makefile":
+        if (name.endswith((".hip", ".h")) or name == "Makefile") and (only is None or name in only):
             h.update(name.encode())
             h.update(open(os.path.join(root, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def profile_is_current(config, vals, psha):
+    """A committed profile counts for the tree when the whole of csrc/ hashes to what it recorded, or when the files its own
+    config is compiled from do (`# config_source_sha:` line; vals["_config_sha"])."""
+    if psha == kernel_source_sha():
+        return True
+    return bool(config in CONFIG_SOURCES and vals.get("_config_sha") and vals["_config_sha"] == kernel_source_sha(config))
 
 
 def committed_profile(config, kernel=None):
@@ -139,10 +166,12 @@ def committed_profile(config, kernel=None):
     cands = sorted(n for n in os.listdir(prof_dir) if n.endswith("_%s_pmc_summary.txt" % config))
     if not cands:
         return {}, None, None
-    per_kernel, sha = {}, None
+    per_kernel, sha, csha = {}, None, None
     for line in open(os.path.join(prof_dir, cands[-1])):
         if line.startswith("# kernel_source_sha:"):
             sha = line.split(":", 1)[1].strip()
+        if line.startswith("# config_source_sha:"):
+            csha = line.split(":", 1)[1].strip()
         f = line.split()
         if not line.startswith("#") and len(f) >= 4 and f[-1].startswith("mean="):
             name = " ".join(f[:-3]).replace(" ", "")           # "k_exh_sea16p<3, 5, 36>" -> "k_exh_sea16p<3,5,36>"
@@ -159,6 +188,7 @@ def committed_profile(config, kernel=None):
         name = max(per_kernel, key=lambda n: per_kernel[n].get("GRBM_GUI_ACTIVE", 0.0))
     vals = dict(per_kernel[name])
     vals["_kernel"] = name
+    vals["_config_sha"] = csha
     return vals, sha, cands[-1]
 
 
@@ -789,7 +819,7 @@ def measure(opt, ctx, comm, rank, world):
             "value": ops, "unit": "byte-abs-diff/s", "qsad_issue_peak": QSAD_PEAK_OPS}
     if vals and opt.content == "synthetic":
         reason = None
-        if psha != kernel_source_sha():
+        if not profile_is_current(opt.config, vals, psha):
             reason = "kernel sources changed since %s was taken" % pname
         elif switches:
             reason = "runtime switches set: " + ",".join(switches)

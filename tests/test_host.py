@@ -453,6 +453,8 @@ def test_committed_profiles_belong_to_these_kernels():
     sys.path.insert(0, REPO)
     import bench
     sha = bench.kernel_source_sha()
+    assert set(bench.CONFIG_SOURCES) <= set(bench.CONFIGS) and all(
+        os.path.exists(os.path.join(REPO, "global-motion-estimation_amd", "csrc", f)) for fs in list(bench.CONFIG_SOURCES.values()) + [bench.COMMON_SOURCES] for f in fs)
     plans = {"exh720": "k_exh_sea16p<3,5>", "exh720mse": "k_exh_mfma16<3,3,4>", "exh720mse_vec": "k_exh_sea16p_mse<3,5>", "exh1080": "k_exh_sea16p<5,7>",
              "exh1080mse_mfma": "k_exh_mfma16<5,2,4>",
              "exh1080mse": "k_exh_sea16p_mse<5,7>", "gme720": "k_walk16<1>", "gme1080exh": "k_exh_sea16p_mse<5,7>",
@@ -461,7 +463,11 @@ def test_committed_profiles_belong_to_these_kernels():
              "gme_pan240_bs12fd5": "k_walkq<12,1>"}
     for config, kernel in plans.items():
         vals, psha, name = bench.committed_profile(config, kernel)
-        assert name and psha == sha, "profiles/%s was taken with other kernel sources (%s != %s): re-run tools/final_run.sh <tag> prof" % (name, psha, sha)
+        # the whole of csrc/ as recorded, or -- after a change that cannot reach this config's kernels -- the files they are
+        # compiled from (bench.CONFIG_SOURCES; `# config_source_sha:` in the summary)
+        assert name and bench.profile_is_current(config, vals, psha), \
+            "profiles/%s was taken with other kernel sources (%s != %s, config files %s != %s): re-run tools/final_run.sh <tag> prof" % (
+                name, psha, sha, vals.get("_config_sha"), bench.kernel_source_sha(config))
         assert vals["_kernel"].split("<")[0] == kernel.split("<")[0], (config, vals.get("_kernel"))
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU"):
             assert vals.get(counter, 0) > 0, (config, counter)

@@ -20,6 +20,9 @@ print("# source: %s (rocprofv3 --pmc <counters> --kernel-trace, separate passes)
 try:
     import bench
     print("# kernel_source_sha: %s" % bench.kernel_source_sha())       # bench.py emits these counters only for the same kernels
+    cfg = os.path.basename(os.path.normpath(root))                      # gpurun_out/<tag>/<config>
+    if cfg in bench.CONFIG_SOURCES:
+        print("# config_source_sha: %s" % bench.kernel_source_sha(cfg))  # ... or for the same files of this config's kernels
 except Exception as e:      # noqa: BLE001
     print("# kernel_source_sha: unknown (%r)" % (e,))
 # gpurun merges a call's files INTO the local gpurun_out/: a pass directory re-used by a later profile run holds the CSVs of
