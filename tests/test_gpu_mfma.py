@@ -129,3 +129,36 @@ def test_mfma_bench_sizes_and_vector_kernels_agree(native):
                     assert np.array_equal(mv[p], co.bbme(frames[p], frames[p + 1], 16, sw, 0, 1)), (H, W, kind, p)
             finally:
                 seq.close()
+
+
+def test_mfma_full_batch_equals_vector_unit(native):
+    """bench.py's own batch (2048 resident pairs of 720x480, the synthetic sequence and the reference's real pan240 frames
+    upscaled x2): the matrix-core kernel and the vector unit's elimination kernel -- two independent implementations, the
+    second pinned on the goldens and checked pair by pair in test_gpu_round2.py -- must return the same 2048 fields, and the
+    first and last pair must be the C oracle's."""
+    import bench
+    co = c_oracle()
+    ctx = native.default_context()
+    for kind in ("synthetic", "pan240x2"):
+        if kind == "synthetic":
+            seq = native.Sequence(ctx, 2049, 480, 720)
+            seq.synth(1234)
+            ends = [(seq.read_frame(p), seq.read_frame(p + 1)) for p in (0, 2047)]
+        else:
+            frames, H, W = bench.host_content("pan240x2", 2049, 480, 720)
+            seq = native.Sequence.from_frames(ctx, frames)
+            ends = [(frames[p], frames[p + 1]) for p in (0, 2047)]
+        try:
+            seq.bbme(1, 16, 16, 0, 1)
+            assert ctx.last_bbme_info()["plan"].startswith("k_exh_mfma16<3>"), ctx.last_bbme_info()
+            mv = seq.read_mv().copy()
+            with _env(GME_EXH_MFMA=0):
+                seq.invalidate_pyramids()
+                seq.bbme(1, 16, 16, 0, 1)
+                assert ctx.last_bbme_info()["plan"].startswith("k_exh_sea16p_mse"), ctx.last_bbme_info()
+                vec = seq.read_mv()
+            assert mv.shape[0] == 2048 and np.array_equal(mv, vec), (kind, np.argwhere(mv != vec)[:4])
+            for p, (a, b) in zip((0, 2047), ends):
+                assert np.array_equal(mv[p], co.bbme(a, b, 16, 16, 0, 1)), (kind, p)
+        finally:
+            seq.close()
