@@ -103,6 +103,10 @@ def load_library():
             raise GmeError(
                 "libgme_hip.so is not built (%s). Build it with `make -C %s`; this package has no "
                 "CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+        # multi-process use (one rank per GPU, RCCL over xGMI): the host driver of this pool only supports dmabuf IPC, and
+        # the runtime reads the switch when the first HIP call initialises it -- i.e. after this point.  A value the
+        # launcher exported wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -44,6 +44,20 @@ def test_missing_library_is_an_error(monkeypatch):
         _gme_native.load_library()
 
 
+def test_loading_the_library_selects_dmabuf_ipc_unless_the_launcher_chose():
+    """One rank per GPU over RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool; the HIP runtime reads it at its first
+    call, which is after load_library().  Checked in fresh interpreters: unset -> "0", exported -> left alone."""
+    code = ("import os, sys; sys.path.insert(0, %r); import _gme_native; _gme_native.load_library(); "
+            "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % os.path.join(REPO, "global-motion-estimation_amd"))
+    for exported, want in ((None, "0"), ("1", "1")):
+        env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+        if exported is not None:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = exported
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "global-motion-estimation_amd")
     for root, _, files in os.walk(pkg):
